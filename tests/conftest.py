@@ -1,0 +1,84 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# (file stem, family, oracle kwargs)
+GOLDEN_CASES = [
+    ("tcvae_c3_n3_l60_fk21", "tcvae", dict(num_layers=3, slope=0.2)),
+    ("tcvae_c3_n4_l60_fk15", "tcvae", dict(num_layers=4, slope=0.2)),
+    ("tcvae_c2_n2_l30_relu", "tcvae", dict(num_layers=2, slope=0.0)),
+    ("multiscale_c3_l60", "multiscale", dict()),
+    ("mnist_lat15", "mnist", dict()),
+]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(stem):
+    import numpy as np
+    import torch
+
+    z = np.load(os.path.join(GOLDEN, stem + ".npz"))
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = torch.from_numpy(a.copy()) if a.ndim else torch.tensor(a.item(), dtype=torch.int64 if a.dtype.kind == "i" else torch.float32)
+    return out
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(params=GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
+def golden_case(request):
+    stem, family, kw = request.param
+    return stem, family, kw, load_golden(stem)
+
+
+def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5):
+    """Gradient comparison used by every parity test: rtol 1e-3 (BASELINE.json north_star)
+    plus an absolute floor of atol_rel x the largest gradient magnitude in the whole model.
+    The floor is needed because some gradients are pure cancellation noise in fp32 (e.g.
+    the bias of a conv whose outputs are all positive before BatchNorm: true gradient 0)."""
+    import torch
+
+    assert set(got) == set(want), (sorted(set(got) ^ set(want)))
+    gmax = max(float(v.abs().max()) for v in want.values())
+    for k, v in want.items():
+        torch.testing.assert_close(got[k].detach().float().cpu(), v.float(), rtol=rtol, atol=atol_rel * gmax,
+                                   msg=lambda m, k=k: f"grad {k}: {m}")
+
+
+def assert_params_close(got, want, grads0, steps, lr, rtol=2e-4, atol=2e-5, noise_rel=2e-5):
+    """Parameters after `steps` Adam steps.  Adam divides each gradient element by its own
+    running magnitude, so an absolute gradient error e on an element of size |g| moves that
+    parameter by about lr*e/|g| per step (a pure-noise gradient, see assert_grads_close, takes
+    +-lr steps of arbitrary sign).  Per-element tolerance therefore is
+        atol + rtol*|want| + steps*lr*min(1, 10*noise/|g0|),   noise = noise_rel x global max |g0|
+    which is ~2e-5 for well-conditioned elements and at most 2.5*steps*lr for noise elements (two trajectories stepping in opposite directions)."""
+    import torch
+
+    gmax = max(float(v.abs().max()) for v in grads0.values())
+    for k, v in want.items():
+        a = got[k].detach().cpu()
+        if not v.dtype.is_floating_point:
+            assert int(a) == int(v), k
+            continue
+        a = a.float()
+        tol = atol + rtol * v.abs()
+        if k in grads0:
+            tol = tol + 2.5 * steps * lr * torch.clamp(10 * noise_rel * gmax / grads0[k].abs().clamp_min(1e-30), max=1.0)
+        elif "running_" in k:  # running stats see the +-lr drift of noisy biases upstream
+            tol = tol + steps * lr
+        bad = (a - v).abs() > tol
+        assert not bad.any(), f"param {k}: {int(bad.sum())} elements off, max diff {float((a - v).abs().max()):.3e}"
