@@ -1,0 +1,143 @@
+/* vae_amd.h - C ABI of libvae_amd.so: the MI355X (gfx950) VAE training hot path.
+ *
+ * The reference (AnisKadri/VAE) has no FFI: its boundary for this path is the Python
+ * nn.Module duck type.  This library is what sits underneath the drop-in
+ * Python modules in vae_amd/: plain pointers, sizes and a hipStream_t, no torch types.
+ * Every entry point returns 0 on success or a negative VAE_E* code; vae_last_error()
+ * returns a human-readable message for the calling thread's last failure.  All pointers are
+ * DEVICE pointers to fp32 unless stated; all launches go to the given stream and nothing
+ * synchronises or allocates (safe to capture in a hipGraph), except vae_graph_* which own
+ * graph objects.
+ *
+ * The hot path is expressed as a PROGRAM: an array of vae_op records executed in order by
+ * vae_run_forward and in reverse by vae_run_backward.  One op = one fused layer primitive
+ * of the reference model:
+ *
+ *   kind          replaces (reference file:line)
+ *   VAE_OP_CONV   nn.Conv1d / nn.Conv2d + LeakyReLU/ReLU that follows it
+ *                 (Encoders.py:42-43,46-47; multiscale_vae.py:54-63,102-111;
+ *                  vae-checkpoint.ipynb:37-43)
+ *   VAE_OP_CONVT  nn.ConvTranspose1d / 2d + activation / sigmoid
+ *                 (Decoders.py:49-53; multiscale_vae.py:172-181; vae-checkpoint.ipynb:91-104)
+ *   VAE_OP_BN     nn.BatchNorm1d / 2d, train (batch stats, running-stat update) or eval,
+ *                 optional fused ReLU (Encoders.py:44,48; Decoders.py:54; notebook :40-41,92-96)
+ *   VAE_OP_LINEAR nn.Linear (+ReLU) (Encoders.py:51-58,84-85; Decoders.py:41,59; notebook :48-57,84-86)
+ *   VAE_OP_REPARAM reparametrization_trick (vae.py:15-18; multiscale_vae.py:206-209)
+ *   VAE_OP_SLICE0 x[:, :, 0] (Decoders.py:65; multiscale_vae.py:192)
+ *   VAE_OP_ELBO   criterion: MSE-sum or BCE-sum reconstruction + analytic KL
+ *                 (train.py:39-48; vae-checkpoint.ipynb:141-151)
+ *
+ * Buffer references ("refs") are int64: (space << 56) | offset_in_floats.  `space` indexes
+ * the `bases` pointer table handed to vae_run_*; by convention of the Python host:
+ *   0 WORK (activations + activation grads)   1 PARAM (flat parameters)
+ *   2 GRAD (flat parameter grads, same offsets as PARAM)   3 STATE (BN running stats, rng)
+ *   4.. EXT (caller tensors: x, eps, outputs, incoming grads)
+ * A ref of -1 means "absent".  Extents are validated on the host against `base_sizes`
+ * before any launch.
+ */
+#ifndef VAE_AMD_H
+#define VAE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vae_stream_t; /* == hipStream_t */
+
+enum {
+    VAE_OK = 0,
+    VAE_EINVAL = -1,   /* bad argument / shape mismatch / out-of-bounds ref */
+    VAE_EHIP = -2,     /* a HIP runtime call failed */
+    VAE_ENODEV = -3,   /* no gfx950 device */
+};
+
+enum { VAE_OP_CONV = 1, VAE_OP_CONVT = 2, VAE_OP_BN = 3, VAE_OP_LINEAR = 4,
+       VAE_OP_REPARAM = 5, VAE_OP_SLICE0 = 6, VAE_OP_ELBO = 7 };
+enum { VAE_ACT_NONE = 0, VAE_ACT_LEAKY = 1 /* slope in f[0]; 0 => ReLU */, VAE_ACT_SIGMOID = 2 };
+enum {
+    VAE_F_ACC_DIN = 1,     /* LINEAR/CONV: input grad is accumulated (+=), input has >1 consumer */
+    VAE_F_BN_RELU = 2,     /* BN: ReLU fused after normalisation (notebook Conv->BN->ReLU) */
+    VAE_F_KL_GRAD = 4,     /* REPARAM bwd: add d(KL)/dmu, d(KL)/dlogvar scaled by the ELBO op's g */
+    VAE_F_EXT_GRAD = 8,    /* REPARAM bwd: add incoming grads r[7], r[8] (autograd path) */
+    VAE_F_BCE = 16,        /* ELBO: BCE-sum reconstruction (else MSE-sum) */
+};
+
+/* One program op.  Field use per kind ("-" unused):
+ *  CONV/CONVT r: 0 in, 1 out, 2 din(-1: none), 3 dout, 4 w, 5 b (w,b: PARAM refs), 6 partials (WORK,
+ *                2*Cout*VAE_MAX_CHUNKS floats of scratch for the bias-gradient reduction)
+ *             d: 0 Cin 1 H 2 W 3 Cout 4 OH 5 OW 6 KH 7 KW 8 sh 9 sw 10 ph 11 pw
+ *             act, f[0]=slope.  Weight layout: CONV [Cout][Cin][KH][KW], CONVT [Cin][Cout][KH][KW].
+ *  BN         r: 0 in, 1 out, 2 din, 3 dout, 4 gamma, 5 beta, 6 save (WORK, 4*C floats: mean,rstd,
+ *                sum_dy/n, sum_dy_xhat/n), 7 running_mean, 8 running_var (STATE), 9 partials (WORK,
+ *                2*C*VAE_MAX_CHUNKS floats)
+ *             d: 0 C, 1 HW.   f[0]=eps f[1]=momentum
+ *  LINEAR     r: 0 in, 1 out, 2 din(-1), 3 dout, 4 w [N][K], 5 b, 6 partials (WORK, 2*N*VAE_MAX_CHUNKS)
+ *             d: 0 K, 1 N, 2 ld_in, 3 ld_out, 4 ld_din, 5 ld_dout.   act NONE or LEAKY(0)
+ *  REPARAM    r: 0 mu, 1 logvar, 2 eps, 3 z, 4 dz, 5 dmu(out), 6 dlogvar(out), 7 g_mu, 8 g_logvar
+ *                (EXT_GRAD), 9 gscale (device float, KL_GRAD; -1 => 1.0)
+ *             d: 0 latent (row length; mu/logvar/eps/z contiguous [B][latent])
+ *  SLICE0     r: 0 in [B][C][L], 1 out [B][C], 2 din, 3 dout.   d: 0 C, 1 L
+ *  ELBO       r: 0 x_rec, 1 target, 2 mu, 3 logvar, 4 out (3 floats: loss, recon, kld; plus
+ *                out[3] += loss when d[5]), 5 dx_rec, 6 partials (WORK, 2*VAE_ELBO_BLOCKS floats),
+ *                7 gscale (device float, -1 => 1.0)
+ *             d: 0 n_per_sample, 1 target batch stride, 2 target element stride, 3 latent,
+ *                4 - , 5 accumulate running loss into out[3]
+ */
+typedef struct vae_op {
+    int32_t kind;
+    int32_t act;
+    int32_t flags;
+    int32_t reserved;
+    int64_t r[12];
+    int32_t d[16];
+    float f[4];
+} vae_op;
+
+#define VAE_MAX_CHUNKS 64
+#define VAE_ELBO_BLOCKS 256
+
+const char* vae_last_error(void);
+/* Queries device 0..: returns 0 if the current device is gfx950, VAE_ENODEV otherwise. */
+int vae_check_device(void);
+
+/* Executes ops[0..n) forward / backward for a batch of B samples.
+ * bases[i] / base_sizes[i] (floats) describe the address spaces; training != 0 selects
+ * BatchNorm batch statistics + running-stat update. */
+int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                    int n_bases, int B, int training, vae_stream_t stream);
+int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                     int n_bases, int B, vae_stream_t stream);
+
+/* Standalone criterion (autograd path).  Replaces train.py:39-48 / notebook :141-151.
+ * out: 3 floats (loss, recon, kld).  partials: >= 2*VAE_ELBO_BLOCKS floats of scratch.
+ * Target element (b, j) is at target[b*t_sb + j*t_se]. */
+int vae_elbo_forward(const float* x_rec, const float* target, const float* mu, const float* logvar,
+                     float* out, float* partials, int B, int n_per_sample, int64_t t_sb, int64_t t_se,
+                     int latent, int bce, vae_stream_t stream);
+int vae_elbo_backward(const float* x_rec, const float* target, const float* mu, const float* logvar,
+                      const float* gscale, float* dx_rec, float* dmu, float* dlogvar, int B,
+                      int n_per_sample, int64_t t_sb, int64_t t_se, int latent, int bce,
+                      vae_stream_t stream);
+
+/* Fused flat Adam (torch.optim.Adam defaults semantics; draft_pipe.py:132, notebook :249).
+ * tick: device int32 step counter, incremented by the kernel chain (graph-replay safe). */
+int vae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int32_t* tick, vae_stream_t stream);
+
+/* eps ~ N(0,1): Philox4x32-10 + Box-Muller; rng = device uint64[2] {seed, offset}; offset is
+ * advanced on the device (replaces torch.randn_like at vae.py:17). */
+int vae_randn(float* out, int64_t n, uint64_t* rng, vae_stream_t stream);
+
+/* hipGraph capture of an arbitrary sequence of the calls above: begin, issue calls on the
+ * returned stream, end -> handle; launch replays on `stream`. */
+int vae_graph_begin(vae_stream_t* capture_stream);
+int vae_graph_end(void** graph_handle);
+int vae_graph_launch(void* graph_handle, vae_stream_t stream);
+int vae_graph_destroy(void* graph_handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,96 @@
+"""ctypes binding of libvae_amd.so (C ABI: include/vae_amd.h).
+
+There is no CPU fallback: if the library is missing or the device is not an MI355X the
+import of the first op raises.  torch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvae_amd.so")
+
+# enums (include/vae_amd.h)
+OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE = 1, 2, 4, 8, 16
+MAX_CHUNKS, ELBO_BLOCKS = 64, 256
+SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
+
+
+class VaeOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("act", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("r", ctypes.c_int64 * 12), ("d", ctypes.c_int32 * 16),
+                ("f", ctypes.c_float * 4)]
+
+
+class VaeAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libvae_amd.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VaeAmdError(
+            f"{LIB_PATH} not found: build it with `make -C vae_amd/csrc` (or __graft_entry__.build()). "
+            "vae_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    L.vae_last_error.restype = ctypes.c_char_p
+    L.vae_last_error.argtypes = []
+    L.vae_check_device.argtypes = []
+    L.vae_run_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp]
+    L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
+    L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
+    L.vae_elbo_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
+    L.vae_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]
+    L.vae_randn.argtypes = [vp, i64, vp, vp]
+    L.vae_graph_begin.argtypes = [ctypes.POINTER(vp)]
+    L.vae_graph_end.argtypes = [ctypes.POINTER(vp)]
+    L.vae_graph_launch.argtypes = [vp, vp]
+    L.vae_graph_destroy.argtypes = [vp]
+    for name in ("vae_check_device", "vae_run_forward", "vae_run_backward", "vae_elbo_forward", "vae_elbo_backward",
+                 "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end", "vae_graph_launch",
+                 "vae_graph_destroy"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+EXPORTS = ("vae_last_error", "vae_check_device", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
+           "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end",
+           "vae_graph_launch", "vae_graph_destroy")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VaeAmdError(f"{what} failed ({rc}): {lib().vae_last_error().decode()}")
+
+
+_device_ok = set()
+
+
+def require_device(t):
+    """Every op calls this on one of its tensors: product code runs on an MI355X or not at all."""
+    if not t.is_cuda:
+        raise VaeAmdError(f"vae_amd ops need tensors on an MI355X (got device {t.device}); there is no CPU path")
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if idx not in _device_ok:
+        with torch.cuda.device(idx):
+            check(lib().vae_check_device(), "vae_check_device")
+        _device_ok.add(idx)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

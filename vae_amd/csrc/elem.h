@@ -1,0 +1,194 @@
+// elem.h - fused elementwise / loss / optimiser kernels (HBM-bound, coalesced, grid-stride).
+#pragma once
+#include "common.h"
+
+// z = mu + eps * exp(0.5 * logvar)                                   (vae.py:15-18)
+__global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, float* __restrict__ z,
+                                                     int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        z[i] = fmaf(eps[i], expf(0.5f * logvar[i]), mu[i]);
+}
+
+// dmu = dz [+ g_mu] [+ gs * mu];  dlogvar = dz * eps * 0.5 * exp(0.5 lv) [+ g_lv] [+ gs * 0.5 * (exp(lv) - 1)]
+__global__ __launch_bounds__(256) void reparam_bwd_k(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, const float* __restrict__ dz,
+                                                     const float* g_mu, const float* g_lv,
+                                                     const float* __restrict__ gscale, int kl_grad, float* dmu,
+                                                     float* dlv, int64_t n) {
+    // g_mu/g_lv may alias dmu/dlv (autograd path adds the incoming gradient in place)
+    const float gs = kl_grad ? (gscale != nullptr ? gscale[0] : 1.f) : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float lv = logvar[i], d = dz[i];
+        const float sd = expf(0.5f * lv);
+        float a = d, b = d * eps[i] * 0.5f * sd;
+        if (g_mu != nullptr) {
+            a += g_mu[i];
+            b += g_lv[i];
+        }
+        if (kl_grad) {
+            a = fmaf(gs, mu[i], a);
+            b = fmaf(gs, 0.5f * (sd * sd - 1.f), b);
+        }
+        dmu[i] = a;
+        dlv[i] = b;
+    }
+}
+
+// out[b][c] = in[b][c][0]                                              (Decoders.py:65)
+__global__ __launch_bounds__(256) void slice0_fwd_k(const float* __restrict__ in, float* __restrict__ out,
+                                                    int64_t rows, int L) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i * L];
+}
+__global__ __launch_bounds__(256) void slice0_bwd_k(const float* __restrict__ dout, float* __restrict__ din,
+                                                    int64_t total, int L) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        din[i] = (i % L == 0) ? dout[i / L] : 0.f;
+}
+
+// ---- ELBO ----------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_term(float p, float t) {
+    // torch.nn.functional.binary_cross_entropy clamps each log at -100
+    const float lp = fmaxf(logf(p), -100.f);
+    const float l1 = fmaxf(logf(1.f - p), -100.f);
+    return -(t * lp + (1.f - t) * l1);
+}
+
+// stage 1: per-block partial (recon, kld) sums -> partials[block][2]; grid = VAE_ELBO_BLOCKS
+__global__ __launch_bounds__(256) void elbo_fwd_k(const float* __restrict__ xr, const float* __restrict__ tg,
+                                                  const float* __restrict__ mu, const float* __restrict__ lv,
+                                                  float* __restrict__ partials, int64_t B, int nps, int64_t t_sb,
+                                                  int64_t t_se, int latent, int bce) {
+    __shared__ float sm[4];
+    float rec = 0.f, kl = 0.f;
+    const int64_t nrec = B * nps, nkl = B * latent;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
+        const int64_t b = i / nps;
+        const int j = (int)(i - b * nps);
+        const float p = xr[i], t = tg[b * t_sb + j * t_se];
+        if (bce) rec += bce_term(p, t);
+        else rec = fmaf(p - t, p - t, rec);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nkl; i += stride) {
+        const float m = mu[i], l = lv[i];
+        kl += 1.f + l - m * m - expf(l);
+    }
+    const float r = block_sum_256(rec, sm);
+    const float k = block_sum_256(kl, sm);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = r;
+        partials[2 * blockIdx.x + 1] = -0.5f * k;
+    }
+}
+// stage 2: fixed-order sum -> out[0]=loss, out[1]=recon, out[2]=kld; optionally out[3] += loss
+__global__ __launch_bounds__(256) void elbo_finalize_k(const float* __restrict__ partials, float* __restrict__ out,
+                                                       int nblocks, int accumulate) {
+    __shared__ float sm[4];
+    float r = 0.f, k = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        r += partials[2 * i];
+        k += partials[2 * i + 1];
+    }
+    r = block_sum_256(r, sm);
+    k = block_sum_256(k, sm);
+    if (threadIdx.x == 0) {
+        out[0] = r + k;
+        out[1] = r;
+        out[2] = k;
+        if (accumulate) out[3] += r + k;
+    }
+}
+
+// d(loss)/d(x_rec) (and optionally the KL grads when dmu != nullptr), scaled by gscale[0]
+__global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, const float* __restrict__ tg,
+                                                  const float* __restrict__ mu, const float* __restrict__ lv,
+                                                  const float* __restrict__ gscale, float* __restrict__ dxr,
+                                                  float* __restrict__ dmu, float* __restrict__ dlv, int64_t B,
+                                                  int nps, int64_t t_sb, int64_t t_se, int latent, int bce) {
+    const float gs = gscale != nullptr ? gscale[0] : 1.f;
+    const int64_t nrec = B * nps, nkl = B * latent;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
+        const int64_t b = i / nps;
+        const int j = (int)(i - b * nps);
+        const float p = xr[i], t = tg[b * t_sb + j * t_se];
+        float g;
+        if (bce) g = (p - t) / fmaxf((1.f - p) * p, 1e-12f);  // torch's binary_cross_entropy_backward
+        else g = 2.f * (p - t);
+        dxr[i] = g * gs;
+    }
+    if (dmu != nullptr)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nkl; i += stride) {
+            dmu[i] = gs * mu[i];
+            dlv[i] = gs * 0.5f * (expf(lv[i]) - 1.f);
+        }
+}
+
+// ---- Adam ----------------------------------------------------------------------------------
+// tick[0] = step count t (int32, device).  adam_tick_k bumps it once per optimiser step, so a
+// captured graph replays with the right bias correction.  bc[0] = 1-b1^t, bc[1] = 1-b2^t.
+__global__ void adam_tick_k(int32_t* tick, float* bc, float beta1, float beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = tick[0] + 1;
+        tick[0] = t;
+        bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+        bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+}
+__global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float beta1, float beta2, float eps,
+                                                   const float* __restrict__ bc) {
+    const float step = lr / bc[0];
+    const float rs2 = rsqrtf(bc[1]);  // torch: denom = sqrt(v)/sqrt(bc2) + eps
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
+        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) * rs2 + eps);
+    }
+}
+
+// ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+}
+__global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t n, const uint64_t* __restrict__ rng) {
+    const uint64_t seed = rng[0], base = rng[1];
+    const int64_t nquad = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = base + (uint64_t)q;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5eed0001u, c3 = 0u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+        float s0, cs0, s1, cs1;
+        sincosf(6.2831853071795865f * u1, &s0, &cs0);
+        sincosf(6.2831853071795865f * u3, &s1, &cs1);
+        const float v[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < n) out[4 * q + j] = v[j];
+    }
+}
+// advance the offset after a draw (single lane; vector store)
+__global__ void rng_advance_k(uint64_t* rng, uint64_t nquad) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += nquad;
+}

@@ -1,0 +1,226 @@
+"""Program builder and runner: the host side of libvae_amd's op-program executor.
+
+A model's forward is lowered ONCE per (batch size, mode) into an array of `vae_op` records
+(include/vae_amd.h) plus a workspace layout; running it is a single C call for the whole
+forward and one for the whole backward, so Python is not on the per-layer path.
+
+Address spaces: 0 WORK (activations, activation grads, scratch), 1 PARAM (flat parameters),
+2 GRAD (flat parameter grads), 3 STATE (BatchNorm running statistics), 4.. one per program input.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+ALIGN = 64  # floats; every workspace buffer starts on a 256-byte boundary
+
+
+def mkref(space, off):
+    return (space << 56) | off
+
+
+class Buf:
+    """A [B][ld] fp32 matrix view inside an address space (ld = floats per sample)."""
+
+    __slots__ = ("ref", "gref", "ld", "n")
+
+    def __init__(self, ref, gref, ld, n):
+        self.ref, self.gref, self.ld, self.n = ref, gref, ld, n
+
+    def cols(self, off, n):
+        assert 0 <= off and off + n <= self.n
+        return Buf(self.ref + off, self.gref + off if self.gref >= 0 else -1, self.ld, n)
+
+
+class ProgramBuilder:
+    def __init__(self, B, param_off, state_off, want_grads=True):
+        """param_off / state_off: dict id(tensor) -> float offset in the flat PARAM / STATE buffers."""
+        self.B = B
+        self.ops = []
+        self.work_size = 0
+        self.param_off, self.state_off = param_off, state_off
+        self.want_grads = want_grads
+        self.inputs = []  # (name, per_sample, Buf)
+        self.outputs = {}  # name -> (Buf, shape_per_sample)
+        self.scratch_need = 2 * L.ELBO_BLOCKS
+        self._scratch_ops = []  # (op, slot, floats)
+
+    # -- allocation ---------------------------------------------------------------------
+    def _alloc(self, floats):
+        off = self.work_size
+        self.work_size += (floats + ALIGN - 1) // ALIGN * ALIGN
+        return off
+
+    def act(self, per_sample, grad=True):
+        ref = mkref(L.SP_WORK, self._alloc(per_sample * self.B))
+        gref = mkref(L.SP_WORK, self._alloc(per_sample * self.B)) if (grad and self.want_grads) else -1
+        return Buf(ref, gref, per_sample, per_sample)
+
+    def fixed(self, floats):
+        return mkref(L.SP_WORK, self._alloc(floats))
+
+    def input(self, name, per_sample, grad=False):
+        space = L.SP_EXT0 + len(self.inputs)
+        gref = mkref(L.SP_WORK, self._alloc(per_sample * self.B)) if (grad and self.want_grads) else -1
+        buf = Buf(mkref(space, 0), gref, per_sample, per_sample)
+        self.inputs.append((name, per_sample, buf))
+        return buf
+
+    def output(self, name, buf, shape):
+        self.outputs[name] = (buf, tuple(shape))
+
+    def param(self, t):
+        return mkref(L.SP_PARAM, self.param_off[id(t)])
+
+    def state(self, t):
+        return mkref(L.SP_STATE, self.state_off[id(t)])
+
+    def _op(self, kind, act=L.ACT_NONE, flags=0, r=(), d=(), f=()):
+        op = L.VaeOp()
+        op.kind, op.act, op.flags = kind, act, flags
+        for i in range(12):
+            op.r[i] = -1
+        for i, v in enumerate(r):
+            op.r[i] = v
+        for i, v in enumerate(d):
+            op.d[i] = v
+        for i, v in enumerate(f):
+            op.f[i] = v
+        self.ops.append(op)
+        return op
+
+    def _need_scratch(self, op, slot, floats):
+        self.scratch_need = max(self.scratch_need, floats)
+        self._scratch_ops.append((op, slot))
+
+    # -- ops ------------------------------------------------------------------------------
+    def conv(self, x, w, b, cin, hw, cout, k, stride, pad, transposed=False, out_pad=(0, 0), act=L.ACT_NONE,
+             slope=0.0, need_din=True):
+        """x: Buf of cin*H*W per sample.  hw/k/stride/pad/out_pad are (h, w) pairs.  Returns (y, (OH, OW))."""
+        (H, W), (KH, KW), (sh, sw), (ph, pw) = hw, k, stride, pad
+        if transposed:
+            OH = (H - 1) * sh - 2 * ph + KH + out_pad[0]
+            OW = (W - 1) * sw - 2 * pw + KW + out_pad[1]
+        else:
+            OH, OW = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+        if OH < 1 or OW < 1:
+            raise ValueError("Window Length is too small in relation to the number of Layers")
+        assert x.n == cin * H * W and x.ld == x.n, "conv input must be a dense [B][C*H*W] buffer"
+        y = self.act(cout * OH * OW)
+        op = self._op(L.OP_CONVT if transposed else L.OP_CONV, act=act,
+                      r=(x.ref, y.ref, x.gref if need_din else -1, y.gref, self.param(w),
+                         self.param(b) if b is not None else -1),
+                      d=(cin, H, W, cout, OH, OW, KH, KW, sh, sw, ph, pw), f=(slope,))
+        self._need_scratch(op, 6, 2 * cout * L.MAX_CHUNKS)
+        return y, (OH, OW)
+
+    def batchnorm(self, x, bn, C, HW, relu=False, eps=1e-5, momentum=0.1):
+        """bn: holder with .weight .bias .running_mean .running_var"""
+        assert x.n == C * HW and x.ld == x.n
+        y = self.act(C * HW)
+        save = self.fixed(4 * C)
+        op = self._op(L.OP_BN, flags=L.F_BN_RELU if relu else 0,
+                      r=(x.ref, y.ref, x.gref, y.gref, self.param(bn.weight), self.param(bn.bias), save,
+                         self.state(bn.running_mean), self.state(bn.running_var)),
+                      d=(C, HW), f=(eps, momentum))
+        self._need_scratch(op, 9, 2 * C * L.MAX_CHUNKS)
+        return y
+
+    def linear(self, x, w, b, K, N, out=None, act=L.ACT_NONE, acc_din=False, need_din=True):
+        assert x.n == K, (x.n, K)
+        y = out if out is not None else self.act(N)
+        assert y.n == N
+        op = self._op(L.OP_LINEAR, act=act, flags=L.F_ACC_DIN if acc_din else 0,
+                      r=(x.ref, y.ref, x.gref if need_din else -1, y.gref, self.param(w),
+                         self.param(b) if b is not None else -1),
+                      d=(K, N, x.ld, y.ld, x.ld, y.ld), f=(0.0,))
+        self._need_scratch(op, 6, 2 * N * L.MAX_CHUNKS)
+        return y
+
+    def reparam(self, mu, logvar, eps, latent, ext_grad=None, kl_grad=False, gscale=-1):
+        """ext_grad: (g_mu Buf, g_logvar Buf) incoming gradients added in backward (autograd path)."""
+        assert mu.ld == latent and logvar.ld == latent and eps.ld == latent
+        z = self.act(latent)
+        flags = (L.F_EXT_GRAD if ext_grad else 0) | (L.F_KL_GRAD if kl_grad else 0)
+        self._op(L.OP_REPARAM, flags=flags,
+                 r=(mu.ref, logvar.ref, eps.ref, z.ref, z.gref, mu.gref, logvar.gref,
+                    ext_grad[0].ref if ext_grad else -1, ext_grad[1].ref if ext_grad else -1, gscale),
+                 d=(latent,))
+        return z
+
+    def slice0(self, x, C, Lw):
+        assert x.n == C * Lw
+        y = self.act(C)
+        self._op(L.OP_SLICE0, r=(x.ref, y.ref, x.gref, y.gref), d=(C, Lw))
+        return y
+
+    def elbo(self, x_rec, target_ref, t_sb, t_se, mu, logvar, latent, bce, accumulate=True):
+        out = self.fixed(4)
+        op = self._op(L.OP_ELBO, flags=L.F_BCE if bce else 0,
+                      r=(x_rec.ref, target_ref, mu.ref, logvar.ref, out, x_rec.gref, -1, -1),
+                      d=(x_rec.n, t_sb, t_se, latent, 0, 1 if accumulate else 0))
+        self._need_scratch(op, 6, 2 * L.ELBO_BLOCKS)
+        return out
+
+    # -- finish ---------------------------------------------------------------------------
+    def build(self):
+        scratch = self.fixed(self.scratch_need)  # shared: ops run back to back on one stream
+        for op, slot in self._scratch_ops:
+            op.r[slot] = scratch
+        arr = (L.VaeOp * len(self.ops))(*self.ops)
+        return CompiledProgram(arr, len(self.ops), self.B, self.work_size, self.inputs, self.outputs)
+
+
+class CompiledProgram:
+    def __init__(self, ops, n_ops, B, work_size, inputs, outputs):
+        self.ops, self.n_ops, self.B, self.work_size = ops, n_ops, B, work_size
+        self.inputs, self.outputs = inputs, outputs
+        self.n_bases = L.SP_EXT0 + len(inputs)
+        self._bases = (ctypes.c_void_p * self.n_bases)()
+        self._sizes = (ctypes.c_int64 * self.n_bases)()
+
+    def new_workspace(self, device):
+        return torch.empty(self.work_size, dtype=torch.float32, device=device)
+
+    def _bind(self, work, params, grads, state, ext):
+        assert work.numel() >= self.work_size and len(ext) == len(self.inputs)
+        tensors = [work, params, grads, state] + list(ext)
+        for i, t in enumerate(tensors):
+            if t is None:
+                self._bases[i], self._sizes[i] = None, 0
+                continue
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda, "program tensors: contiguous fp32 on GPU"
+            self._bases[i], self._sizes[i] = t.data_ptr(), t.numel()
+        for (name, per_sample, _), t in zip(self.inputs, ext):
+            if t.numel() != per_sample * self.B:
+                raise ValueError(f"input '{name}': expected {self.B}x{per_sample} elements, got {tuple(t.shape)}")
+
+    def forward(self, work, params, state, ext, training, stream=None):
+        self._bind(work, params, None, state, ext)
+        L.check(L.lib().vae_run_forward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                        1 if training else 0, stream if stream is not None else L.stream_ptr()),
+                "vae_run_forward")
+
+    def backward(self, work, params, grads, state, ext, stream=None):
+        self._bind(work, params, grads, state, ext)
+        L.check(L.lib().vae_run_backward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                         stream if stream is not None else L.stream_ptr()),
+                "vae_run_backward")
+
+    def view(self, work, buf, shape=None):
+        """Tensor view of a dense WORK buffer ([B][buf.n]); shape = per-sample shape."""
+        assert (buf.ref >> 56) == L.SP_WORK and buf.ld == buf.n
+        off = buf.ref & ((1 << 56) - 1)
+        t = work[off:off + self.B * buf.n]
+        return t.view(self.B, *(shape if shape is not None else (buf.n,)))
+
+    def grad_view(self, work, buf, shape=None):
+        assert buf.gref >= 0 and buf.ld == buf.n
+        off = buf.gref & ((1 << 56) - 1)
+        t = work[off:off + self.B * buf.n]
+        return t.view(self.B, *(shape if shape is not None else (buf.n,)))
+
+    def scalar_view(self, work, ref, n):
+        off = ref & ((1 << 56) - 1)
+        return work[off:off + n]

@@ -1,0 +1,241 @@
+"""MI355X drop-ins for train.py: slidingWindow, criterion, train, test (train.py:21-89), the
+notebook's BCE criterion (vae-checkpoint.ipynb:141-151) and the fused train step they use.
+
+Signatures are the reference's.  `train()` keeps its loop shape (per batch: to(device),
+zero_grad, forward, criterion(x_rec, data[:,:,0], mu, logvar), backward, optimizer.step) but,
+when it is handed a vae_amd model + vae_amd criterion + vae_amd.optim.Adam, runs each batch as
+ONE hipGraph replay of {eps draw, forward, ELBO, backward, Adam} (FusedTrainStep) and reads the
+loss back only at the reference's print cadence instead of every step (train.py:67).
+"""
+import ctypes
+
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib as L
+from .optim import Adam
+from .program import ProgramBuilder
+from .vae import HipVAE
+
+
+class slidingWindow(Dataset):
+    """item i -> data[:, i:i+L]; len = T - L (train.py:21-32)."""
+
+    def __init__(self, data, L):
+        self.data = data
+        self.L = L
+
+    def __getitem__(self, index):
+        if self.data.shape[1] - index >= self.L:
+            return self.data[:, index:index + self.L]
+
+    def __len__(self):
+        return self.data.shape[1] - self.L
+
+
+# ------------------------------------------------------------------------------- criterion
+class _ElboFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recon_x, x, mu, logvar, bce):
+        L.require_device(recon_x)
+        B = recon_x.shape[0]
+        xr = recon_x.detach().float().contiguous().view(B, -1)
+        tg = x.detach().float()
+        tg = tg if tg.dim() == 2 else tg.reshape(B, -1)
+        if tg.shape != xr.shape:
+            raise ValueError(f"criterion: reconstruction {tuple(recon_x.shape)} vs target {tuple(x.shape)}")
+        if tg.stride(0) < 0 or tg.stride(1) < 0:
+            tg = tg.contiguous()
+        m, lv = mu.detach().float().contiguous(), logvar.detach().float().contiguous()
+        out = torch.empty(4, device=xr.device)
+        partials = torch.empty(2 * L.ELBO_BLOCKS, device=xr.device)
+        L.check(L.lib().vae_elbo_forward(L.ptr(xr), L.ptr(tg), L.ptr(m), L.ptr(lv), L.ptr(out), L.ptr(partials), B,
+                                         xr.shape[1], tg.stride(0), tg.stride(1), m.shape[1], int(bce), L.stream_ptr()),
+                "vae_elbo_forward")
+        ctx.saved = (xr, tg, m, lv, bce, recon_x.shape)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, tg, m, lv, bce, shape = ctx.saved
+        B = xr.shape[0]
+        gs = g.detach().float().reshape(1).contiguous()
+        dxr, dmu, dlv = torch.empty_like(xr), torch.empty_like(m), torch.empty_like(lv)
+        L.check(L.lib().vae_elbo_backward(L.ptr(xr), L.ptr(tg), L.ptr(m), L.ptr(lv), L.ptr(gs), L.ptr(dxr), L.ptr(dmu),
+                                          L.ptr(dlv), B, xr.shape[1], tg.stride(0), tg.stride(1), m.shape[1], int(bce),
+                                          L.stream_ptr()), "vae_elbo_backward")
+        return dxr.view(shape), None, dmu, dlv, None
+
+
+def criterion(recon_x, x, mu, logvar):
+    """MSE-sum reconstruction + KL-sum (train.py:39-48); returns a 0-dim tensor."""
+    return _ElboFn.apply(recon_x, x, mu, logvar, False)
+
+
+def criterion_bce(recon_x, x, mu, logvar):
+    """BCE-sum reconstruction + KL-sum, the notebook's criterion (vae-checkpoint.ipynb:141-151)."""
+    return _ElboFn.apply(recon_x, x, mu, logvar, True)
+
+
+criterion.elbo_bce = False
+criterion_bce.elbo_bce = True
+
+
+# ------------------------------------------------------------------------- fused train step
+class FusedTrainStep:
+    """{eps ~ N(0,1), forward, ELBO, backward, Adam} for one batch as a single captured hipGraph.
+
+    Inputs are copied into static device buffers (graph nodes hold fixed addresses); loss of
+    the last step and the running sum live in device memory (`loss`, `total`)."""
+
+    def __init__(self, model, optimizer, B, device, bce=None, use_graph=True):
+        if not isinstance(model, HipVAE) or not isinstance(optimizer, Adam):
+            raise TypeError("FusedTrainStep needs a vae_amd VAE model and vae_amd.optim.Adam")
+        self.model, self.opt, self.B, self.device = model, optimizer, B, torch.device(device)
+        self.bce = model.elbo_bce if bce is None else bool(bce)
+        self.group = optimizer.param_groups[0]
+        flat, sflat = model.pack(self.device)
+        plist = [p for _, p in model.named_parameters()]
+        if len(optimizer.param_groups) != 1 or [id(p) for p in self.group["params"]] != [id(p) for p in plist]:
+            raise ValueError("fused step: the optimizer must hold exactly model.parameters() in one group")
+        self.flat, self.sflat = flat, sflat
+        self.m, self.v, self.tick = optimizer.flat_state(self.group, flat)
+        self.grads = torch.zeros_like(flat)
+        for p, o in zip(plist, [model._param_off[id(p)] for p in plist]):
+            p.grad = self.grads[o:o + p.numel()].view(p.shape)  # p.grad stays meaningful for callers
+        b = ProgramBuilder(B, model._param_off, model._state_off, want_grads=True)
+        x = b.input("x", model._numel(model.in_shape))
+        eps = b.input("eps", model.latent_total)
+        mu, logvar = b.act(model.latent_total), b.act(model.latent_total)
+        model.emit_encoder(b, x, mu, logvar)
+        z = b.reparam(mu, logvar, eps, model.latent_total, kl_grad=True)
+        x_rec = model.emit_decoder(b, z)
+        t_sb, t_se = model.target_strides()
+        self.out_ref = b.elbo(x_rec, x.ref, t_sb, t_se, mu, logvar, model.latent_total, self.bce)
+        self.prog = b.build()
+        self.bufs = dict(x_rec=(x_rec, model.out_shape), mu=(mu, (model.latent_total,)),
+                         logvar=(logvar, (model.latent_total,)))
+        self.work = self.prog.new_workspace(self.device)
+        self.work.zero_()
+        self.x = torch.zeros((B,) + tuple(model.in_shape), device=self.device)
+        self.eps = torch.zeros(B, model.latent_total, device=self.device)
+        out = self.prog.scalar_view(self.work, self.out_ref, 4)
+        self.loss, self.total = out[0:1], out[3:4]
+        self.rng = model._rng_state(self.device)
+        self.inject_eps = False  # tests set this and fill self.eps themselves
+        self.graph = None
+        self.use_graph = use_graph
+        self.steps = 0
+
+    def _enqueue(self, stream):
+        if not self.inject_eps:
+            L.check(L.lib().vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
+        ext = [self.x.view(self.B, -1), self.eps]
+        self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
+        self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
+        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream)
+
+    def _capture(self):
+        cs = ctypes.c_void_p()
+        L.check(L.lib().vae_graph_begin(ctypes.byref(cs)), "vae_graph_begin")
+        try:
+            self._enqueue(cs)
+        finally:
+            h = ctypes.c_void_p()
+            rc = L.lib().vae_graph_end(ctypes.byref(h))
+        L.check(rc, "vae_graph_end")
+        self.graph = h
+
+    def step(self, x=None):
+        """Runs one train step on batch x (None: reuse the resident batch).  Returns the device
+        1-element loss tensor of this step (overwritten by the next step)."""
+        if x is not None:
+            if x.shape != self.x.shape:
+                raise ValueError(f"fused step was built for batches {tuple(self.x.shape)}, got {tuple(x.shape)}")
+            self.x.copy_(x, non_blocking=True)
+        if self.use_graph:
+            if self.graph is None or self._captured_inject != self.inject_eps:
+                if self.graph is not None:
+                    L.lib().vae_graph_destroy(self.graph)
+                self._captured_inject = self.inject_eps
+                torch.cuda.current_stream().synchronize()
+                self._capture()
+            L.check(L.lib().vae_graph_launch(self.graph, L.stream_ptr()), "vae_graph_launch")
+        else:
+            self._enqueue(L.stream_ptr())
+        self.steps += 1
+        for m in self.model._bn_holders():
+            m._pending += 1
+        return self.loss
+
+    def output(self, name):
+        buf, shape = self.bufs[name]
+        return self.prog.view(self.work, buf, shape)
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                L.lib().vae_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+def _fused_stepper(model, criterion_fn, optimizer, data):
+    """Returns a FusedTrainStep when model/criterion/optimizer are all vae_amd's, else None."""
+    if not (isinstance(model, HipVAE) and isinstance(optimizer, Adam) and criterion_fn in (criterion, criterion_bce)):
+        return None
+    key = (data.shape[0], id(optimizer), criterion_fn.elbo_bce, str(data.device))
+    st = model.__dict__.get("_stepper")
+    if st is None or st[0] != key:
+        st = (key, FusedTrainStep(model, optimizer, data.shape[0], data.device, bce=criterion_fn.elbo_bce))
+        model.__dict__["_stepper"] = st
+    return st[1]
+
+
+def _unpack(batch):
+    return batch[0] if isinstance(batch, (tuple, list)) else batch  # notebook loaders yield (data, label)
+
+
+def train(model, train_loader, criterion, optimizer, device, epoch):
+    """One epoch (train.py:51-72).  Prints the reference's progress lines."""
+    model.train()
+    total_dev, total_host = None, 0.0
+    n_batches = len(train_loader)
+    for batch_idx, batch in enumerate(train_loader):
+        data = _unpack(batch).to(device, non_blocking=True)
+        stepper = _fused_stepper(model, criterion, optimizer, data)
+        if stepper is not None:
+            loss = stepper.step(data)
+            total_dev = loss.clone() if total_dev is None else total_dev.add_(loss)
+        else:  # generic autograd path (foreign criterion/optimizer, ragged last batch of another size...)
+            optimizer.zero_grad()
+            x_rec, mu, logvar = model(data)
+            target = data[:, :, 0] if data.dim() == 3 else data
+            loss = criterion(x_rec, target, mu, logvar)
+            loss.backward()
+            optimizer.step()
+            total_dev = loss.detach().clone().reshape(1) if total_dev is None else total_dev.add_(loss.detach())
+        if batch_idx % 100 == 0:
+            print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {:.6f}'.format(
+                epoch, batch_idx * len(data), len(train_loader.dataset),
+                100. * batch_idx / n_batches, loss.item() / len(data)))
+    if total_dev is not None:
+        total_host = float(total_dev.item())
+    print('====> Epoch: {} Average loss: {:.4f}'.format(epoch, total_host / len(train_loader.dataset)))
+    return total_host / len(train_loader.dataset)
+
+
+def test(model, test_loader, criterion, device):
+    """Eval-mode loss per sample (train.py:75-89): BatchNorm uses running stats, eps still drawn."""
+    model.eval()
+    total = None
+    with torch.no_grad():
+        for batch in test_loader:
+            data = _unpack(batch).to(device, non_blocking=True)
+            x_rec, mu, logvar = model(data)
+            target = data[:, :, 0] if data.dim() == 3 else data
+            loss = criterion(x_rec, target, mu, logvar)
+            total = loss.detach().clone() if total is None else total.add_(loss)
+    test_loss = (float(total.item()) if total is not None else 0.0) / len(test_loader.dataset)
+    print('====> Test set loss: {:.4f}'.format(test_loss))
+    return test_loss
