@@ -1,0 +1,101 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared
+symbol, modules mirror the reference's constructor/state_dict contract, and the product
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, sub
+
+
+def test_library_exports_every_declared_symbol():
+    from vae_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build with make -C vae_amd/csrc"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "vae_amd.h")).read()
+    declared = set(re.findall(r"\b(vae_[a-z_]+)\s*\(", header)) - {"vae_op"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(_lib.VaeOp) == 192  # must match struct vae_op
+
+
+def _build(stem):
+    import vae_amd
+    from vae_amd.Decoders import LongShort_TCVAE_Decoder
+    from vae_amd.Encoders import LongShort_TCVAE_Encoder
+    if stem.startswith("tcvae"):
+        C, N, Lw, fk, slope, lat = {"tcvae_c3_n3_l60_fk21": (3, 3, 60, 21, 0.2, 15),
+                                    "tcvae_c3_n4_l60_fk15": (3, 4, 60, 15, 0.2, 15),
+                                    "tcvae_c2_n2_l30_relu": (2, 2, 30, None, 0.0, 4)}[stem]
+        return vae_amd.VariationalAutoencoder(input_size=C, hidden_size=30, num_layers=N, latent_dims=lat,
+                                              v_encoder=LongShort_TCVAE_Encoder, v_decoder=LongShort_TCVAE_Decoder,
+                                              L=Lw, slope=slope, first_kernel=fk)
+    if stem.startswith("multiscale"):
+        return vae_amd.multiscale_vae.vae(3, 60, 15)
+    return vae_amd.mnist_vae.VariationalAutoencoder(15)
+
+
+SEEDS = {"tcvae_c3_n3_l60_fk21": 11, "tcvae_c3_n4_l60_fk15": 12, "tcvae_c2_n2_l30_relu": 13,
+         "multiscale_c3_l60": 14, "mnist_lat15": 15}
+
+
+def test_state_dict_keys_shapes_and_seeded_init_match_reference(golden_case):
+    """Same constructor call under the same torch seed gives the reference's state_dict: same
+    keys, shapes AND values (parameter creation order and init distributions are mirrored)."""
+    stem, family, kw, g = golden_case
+    torch.manual_seed(SEEDS[stem])
+    m = _build(stem)
+    want = sub(g, "sd/")
+    got = m.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    for k, v in want.items():
+        assert got[k].shape == v.shape, k
+        torch.testing.assert_close(got[k].float(), v.float(), rtol=0, atol=0, msg=lambda s, k=k: f"{k}: {s}")
+    m.load_state_dict(want)  # strict load works
+
+
+def test_lin_size_and_too_short_window():
+    from vae_amd.Encoders import TCVAE_Encoder, lin_size
+    assert lin_size(60, 3) * 3 == 126 and lin_size(60, 3, 21) * 3 == 90
+    with pytest.raises(ValueError):
+        lin_size(8, 5)
+    with pytest.raises(ValueError):
+        TCVAE_Encoder(3, 5, 4, L=8)
+
+
+def test_no_cpu_fallback():
+    import vae_amd
+    m = _build("tcvae_c2_n2_l30_relu")
+    with pytest.raises(vae_amd.VaeAmdError):
+        m(torch.zeros(2, 2, 30))
+    with pytest.raises(vae_amd.VaeAmdError):
+        vae_amd.train.criterion(torch.zeros(2, 2), torch.zeros(2, 2), torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_program_layout_is_consistent():
+    """Lowering a model on CPU (no launch): every op's refs fall inside the declared spaces."""
+    from vae_amd import _lib as L
+    m = _build("mnist_lat15")
+    params = [p for _, p in m.named_parameters()]
+    m._param_off, off = {}, 0
+    for p in params:
+        m._param_off[id(p)] = off
+        off += (p.numel() + 3) // 4 * 4
+    m._state_off, soff = {}, 0
+    for b_ in m._float_buffers():
+        m._state_off[id(b_)] = soff
+        soff += (b_.numel() + 3) // 4 * 4
+    from vae_amd.program import ProgramBuilder
+    b = ProgramBuilder(32, m._param_off, m._state_off)
+    m.emit_program(b, True)
+    prog = b.build()
+    assert prog.n_ops == 16 and prog.work_size > 0
+    sizes = {L.SP_WORK: prog.work_size, L.SP_PARAM: off, L.SP_GRAD: off, L.SP_STATE: soff}
+    for op in prog.ops:
+        for r in op.r:
+            if r >= 0 and (r >> 56) in sizes:
+                assert (r & ((1 << 56) - 1)) < sizes[r >> 56]

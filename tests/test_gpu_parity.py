@@ -1,0 +1,175 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors the
+reference produced and against the CPU oracle on fresh seeded inputs.
+
+Tolerances (BASELINE.json north_star): forward outputs, ELBO terms and gradients within
+rtol 1e-3 in fp32; gradients additionally get the cancellation floor documented in
+conftest.assert_grads_close."""
+import pytest
+import torch
+
+from conftest import assert_grads_close, assert_params_close, load_golden, sub
+from test_cpu_host import _build
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+RTOL = 1e-3
+
+
+def close(a, b, rtol=RTOL, atol=1e-4):
+    torch.testing.assert_close(a.detach().float().cpu(), b.float(), rtol=rtol, atol=atol)
+
+
+def _crit(family):
+    import vae_amd
+    return vae_amd.train.criterion_bce if family == "mnist" else vae_amd.train.criterion
+
+
+def _target(family, x):
+    return x if family == "mnist" else x[:, :, 0]
+
+
+def test_forward_loss_grads_match_reference(golden_case):
+    stem, family, kw, g = golden_case
+    m = _build(stem)
+    m.load_state_dict(sub(g, "sd/"))
+    m.to(DEV).train()
+    x = g["x"].to(DEV)
+    x_rec, mu, logvar = m(x, eps=g["eps0"].to(DEV))
+    close(x_rec, g["out/x_rec"])
+    close(mu, g["out/mu"])
+    close(logvar, g["out/logvar"])
+    loss = _crit(family)(x_rec, _target(family, x), mu, logvar)
+    close(loss, g["loss0"], atol=1e-2)
+    loss.backward()
+    got = {k: p.grad for k, p in m.named_parameters()}
+    assert_grads_close(got, sub(g, "grad/"))
+    sd = m.state_dict()
+    for k, v in sub(g, "sd1/").items():
+        close(sd[k], v, atol=1e-5)
+
+
+def test_autograd_adam_trajectory(golden_case):
+    """zero_grad / forward / criterion / backward / vae_amd.optim.Adam.step, 3 steps."""
+    import vae_amd
+    stem, family, kw, g = golden_case
+    m = _build(stem)
+    m.load_state_dict(sub(g, "sd/"))
+    m.to(DEV).train()
+    opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
+    x = g["x"].to(DEV)
+    for step in range(3):
+        opt.zero_grad()
+        x_rec, mu, logvar = m(x, eps=g[f"eps{step}"].to(DEV))
+        loss = _crit(family)(x_rec, _target(family, x), mu, logvar)
+        loss.backward()
+        opt.step()
+        close(loss, g[f"loss{step}"], rtol=2e-3, atol=1e-2)
+    assert_params_close(m.state_dict(), sub(g, "sd3/"), sub(g, "grad/"), steps=3, lr=1e-3)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_train_step_trajectory(golden_case, use_graph):
+    """The fused {forward, ELBO, backward, Adam} step (eager and as a hipGraph replay)."""
+    import vae_amd
+    from vae_amd.train import FusedTrainStep
+    stem, family, kw, g = golden_case
+    m = _build(stem)
+    m.load_state_dict(sub(g, "sd/"))
+    m.to(DEV).train()
+    opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
+    x = g["x"].to(DEV)
+    st = FusedTrainStep(m, opt, x.shape[0], DEV, use_graph=use_graph)
+    st.inject_eps = True
+    total = 0.0
+    for step in range(3):
+        st.eps.copy_(g[f"eps{step}"])
+        loss = st.step(x)
+        want = g[f"loss{step}"].item()
+        assert abs(loss.item() - want) <= 2e-3 * abs(want) + 1e-2
+        total += want
+        if step == 0:
+            close(st.output("x_rec"), g["out/x_rec"])
+            got = {k: p.grad.clone() for k, p in m.named_parameters()}
+            # p.grad aliases the fused gradient buffer of the LAST step: compare right after step 0
+            assert_grads_close(got, sub(g, "grad/"))
+    assert abs(st.total.item() - total) <= 2e-3 * abs(total)
+    assert_params_close(m.state_dict(), sub(g, "sd3/"), sub(g, "grad/"), steps=3, lr=1e-3)
+
+
+def test_eval_forward(golden_case):
+    stem, family, kw, g = golden_case
+    m = _build(stem)
+    m.load_state_dict(sub(g, "sd3/"))
+    m.to(DEV).eval()
+    x = g["x"].to(DEV)
+    with torch.no_grad():
+        x_rec, mu, logvar = m(x, eps=g["eps_eval"].to(DEV))
+        loss = _crit(family)(x_rec, _target(family, x), mu, logvar)
+    close(x_rec, g["eval/x_rec"])
+    close(mu, g["eval/mu"])
+    close(logvar, g["eval/logvar"])
+    close(loss, g["eval/loss"], atol=1e-2)
+
+
+@pytest.mark.parametrize("stem,family,kw,B", [
+    ("mnist_lat15", "mnist", {}, 300),
+    ("multiscale_c3_l60", "multiscale", {}, 517),
+    ("tcvae_c3_n3_l60_fk21", "tcvae", dict(num_layers=3, slope=0.2), 1000),
+])
+def test_against_oracle_at_larger_batch(stem, family, kw, B):
+    """Fresh seeded inputs at ragged batch sizes (exercise tile edges, multi-chunk reductions and
+    split-K): HIP path vs the CPU oracle on identical weights, batch and eps."""
+    from oracle import vae_oracle as O
+    g = load_golden(stem)
+    sd = sub(g, "sd/")
+    gen = torch.Generator().manual_seed(7)
+    if family == "mnist":
+        x = torch.rand(B, 1, 28, 28, generator=gen)
+    else:
+        x = 50 + 10 * torch.randn(B, 3, 60, generator=gen)
+    lat = g["eps0"].shape[1]
+    eps = torch.randn(B, lat, generator=gen)
+    ref = O.loss_and_grads(family, sd, x, eps, **kw)
+    m = _build(stem)
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    xd = x.to(DEV)
+    x_rec, mu, logvar = m(xd, eps=eps.to(DEV))
+    close(x_rec, ref["x_rec"])
+    close(mu, ref["mu"])
+    close(logvar, ref["logvar"])
+    loss = _crit(family)(x_rec, _target(family, xd), mu, logvar)
+    close(loss, ref["loss"], atol=1e-1)
+    loss.backward()
+    assert_grads_close({k: p.grad for k, p in m.named_parameters()}, ref["grads"])
+
+
+def test_submodule_calls_and_reparam():
+    """utils.py in the reference calls model.encoder / model.decoder / reparametrization_trick directly."""
+    g = load_golden("tcvae_c3_n3_l60_fk21")
+    m = _build("tcvae_c3_n3_l60_fk21")
+    m.load_state_dict(sub(g, "sd/"))
+    m.to(DEV).train()
+    x, eps = g["x"].to(DEV), g["eps0"].to(DEV)
+    mu, logvar = m.encoder(x)
+    close(mu, g["out/mu"])
+    z = m.reparametrization_trick(mu, logvar, eps=eps)
+    close(z, g["out/z"])
+    close(m.decoder(z), g["out/x_rec"])
+    z2 = m.reparametrization_trick(mu, logvar)  # device-drawn eps
+    assert z2.shape == z.shape and torch.isfinite(z2).all()
+    # gradient flows through the three separate calls like through forward()
+    loss = m.decoder(z).sum() + 0.0 * mu.sum()
+    loss.backward()
+    assert all(p.grad is not None for p in m.decoder.parameters())
+
+
+def test_device_randn_moments():
+    from vae_amd.vae import device_randn
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    a = device_randn((1 << 20,), rng, DEV)
+    b = device_randn((1 << 20,), rng, DEV)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a * a * a).mean().item()) < 2e-2 and abs((a ** 4).mean().item() - 3) < 5e-2
+    assert not torch.equal(a, b) and int(rng[1].item()) == 2 * (1 << 18)
