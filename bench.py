@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""bench.py - train samples/s of the VAE hot path on MI355X (driver contract in the task).
+
+N=1 : BASELINE.json configs[1]: notebook MNIST Conv2d VAE, batch 4096, fp32, BCE ELBO, Adam.
+N>1 : configs[3]: same model, data-parallel, global batch 65536 split evenly, gradient
+      all-reduce SUM + synchronised BatchNorm statistics over RCCL.
+One step = eps draw + forward + ELBO + backward + Adam on a synthetic batch resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic figures per sample-step for the MNIST model
+M_FLOP_PER_SAMPLE = 1.89e6
+M_BYTES_PER_SAMPLE = 178e3
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(seconds=15.0, B=4096):
+    """CPU oracle (oracle/vae_oracle.py, a port of the reference train loop) on the host cores:
+    zero_grad/forward/criterion/backward/Adam/loss.item() per step, same workload, bounded sample."""
+    from oracle import vae_oracle as O
+    import vae_amd
+    torch.manual_seed(0)
+    m = vae_amd.mnist_vae.VariationalAutoencoder(15)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    opt = O.Adam(sd, lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 1, 28, 28, generator=g)
+    cores = torch.get_num_threads()
+    O.train_step("mnist", sd, opt, x, torch.randn(B, 15, generator=g))  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        O.train_step("mnist", sd, opt, x, torch.randn(B, 15, generator=g))
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {B} (MNIST VAE fwd+BCE ELBO+bwd+Adam) in {dt:.1f}s, torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vae_amd
+    from vae_amd.train import FusedTrainStep
+
+    B = args.batch or (4096 if world == 1 else 65536 // world)
+    torch.manual_seed(0)
+    model = vae_amd.mnist_vae.VariationalAutoencoder(15).to(dev).train()
+    opt = vae_amd.optim.Adam(model.parameters(), lr=1e-3)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    x = torch.rand(B, 1, 28, 28, device=dev, generator=g)
+    if world == 1:
+        stepper = FusedTrainStep(model, opt, B, dev, use_graph=not args.no_graph)
+    else:
+        from vae_amd.parallel import DataParallelTrainStep
+        stepper = DataParallelTrainStep(model, opt, B, dev)
+    stepper.step(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        stepper.step()
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(stepper.loss.item())
+    if not (loss == loss) or loss <= 0:
+        raise SystemExit(f"loss is {loss}: the step is not training")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        dev_ms = e0.elapsed_time(e1) / args.steps
+        # step-level roofline (materialised-activation traffic model); the per-kernel
+        # figure for the dominant kernel is in DESIGN.md / profiles/
+        achieved = M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9
+        line = {
+            "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam, "
+                                    f"batch {B} per GPU, global batch {B * world}"),
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": "single GPU, whole step as one hipGraph" if world == 1 else f"dp{world} + SyncBN"},
+            "loss_per_sample": loss / B,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "scope": "whole step, 178 KB/sample materialised-activation model"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,14 @@ class HipModule(nn.Module):
         return dict(zip(names, outs))
 
 
+def storage_alias(t):
+    """Second tensor over t's memory with its OWN autograd version counter.  Program outputs are
+    views of the per-call workspace; backward writes gradient regions of that same workspace, and
+    doing so through the original tensor would bump the version the output views share."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape,
+                                                                  t.stride())
+
+
 class _ProgramFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, prog, n_in, *args):
@@ -165,7 +173,7 @@ class _ProgramFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        prog, work = ctx.prog, ctx.work
+        prog, work = ctx.prog, storage_alias(ctx.work)
         for (name, (buf, shape)), g in zip(prog.outputs.items(), gouts):
             gv = prog.grad_view(work, buf, shape)
             if g is None:

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _lib as L
-from .module import HipModule
+from .module import HipModule, storage_alias
 from .program import Buf
 
 
@@ -31,7 +31,7 @@ class _ReparamFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gz):
-        prog, work = ctx.prog, ctx.work
+        prog, work = ctx.prog, storage_alias(ctx.work)
         prog.grad_view(work, prog.outputs["z"][0]).copy_(gz)
         g = torch.empty(4, device=gz.device)
         prog.backward(work, g, g, g[:0], ctx.ext)
