@@ -62,6 +62,10 @@ enum {
     VAE_F_KL_GRAD = 4,     /* REPARAM bwd: add d(KL)/dmu, d(KL)/dlogvar scaled by the ELBO op's g */
     VAE_F_EXT_GRAD = 8,    /* REPARAM bwd: add incoming grads r[7], r[8] (autograd path) */
     VAE_F_BCE = 16,        /* ELBO: BCE-sum reconstruction (else MSE-sum) */
+    VAE_F_IN_RELU = 32,    /* CONV/CONVT fused: ReLU follows the producer's (virtual) BatchNorm */
+    VAE_F_FUSED = 64,      /* CONV/CONVT: LDS-staged MFMA implicit-GEMM kernels; BN: "virtual" (its output is
+                              never materialised: the producer's epilogue takes the statistics, the consumer
+                              normalises on load, and the backward pass is folded the same way) */
 };
 
 /* One program op.  Field use per kind ("-" unused):
@@ -69,9 +73,13 @@ enum {
  *                2*Cout*VAE_MAX_CHUNKS floats of scratch for the bias-gradient reduction)
  *             d: 0 Cin 1 H 2 W 3 Cout 4 OH 5 OW 6 KH 7 KW 8 sh 9 sw 10 ph 11 pw
  *             act, f[0]=slope.  Weight layout: CONV [Cout][Cin][KH][KW], CONVT [Cin][Cout][KH][KW].
- *  BN         r: 0 in, 1 out, 2 din, 3 dout, 4 gamma, 5 beta, 6 save (WORK, 4*C floats: mean,rstd,
- *                sum_dy/n, sum_dy_xhat/n), 7 running_mean, 8 running_var (STATE), 9 partials (WORK,
- *                2*C*VAE_MAX_CHUNKS floats)
+ *             VAE_F_FUSED adds: 7 in_bn (save block of the virtual BN that produced `in`, -1 none; then
+ *             `in`/`din` name that BN's INPUT and its gradient), 8 out_bn (save block of the virtual BN
+ *             that follows, -1 none), 9 running_mean of that BN (statistics pivot); r6 then also holds
+ *             the per-block statistics slab (blocks*2*C floats).
+ *  BN         r: 0 in, 1 out, 2 din, 3 dout, 4 gamma, 5 beta, 6 save (WORK, 8*C floats: mean, rstd,
+ *                scale|sum_dy/n, shift|sum_dy_xhat/n, a, b, c, spare), 7 running_mean, 8 running_var
+ *                (STATE), 9 partials / slab (WORK, shared scratch).  VAE_F_FUSED: 1 and 3 are -1.
  *             d: 0 C, 1 HW.   f[0]=eps f[1]=momentum
  *  LINEAR     r: 0 in, 1 out, 2 din(-1), 3 dout, 4 w [N][K], 5 b, 6 partials (WORK, 2*N*VAE_MAX_CHUNKS)
  *             d: 0 K, 1 N, 2 ld_in, 3 ld_out, 4 ld_din, 5 ld_dout.   act NONE or LEAKY(0)
@@ -109,6 +117,10 @@ int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int
                     int n_bases, int B, int training, vae_stream_t stream);
 int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                      int n_bases, int B, vae_stream_t stream);
+
+/* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
+ * the Python program builder; no GPU needed). */
+int vae_conv_fused_ok(const vae_op* op, int B);
 
 /* Standalone criterion (autograd path).  Replaces train.py:39-48 / notebook :141-151.
  * out: 3 floats (loss, recon, kld).  partials: >= 2*VAE_ELBO_BLOCKS floats of scratch.

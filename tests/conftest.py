@@ -45,18 +45,29 @@ def golden_case(request):
     return stem, family, kw, load_golden(stem)
 
 
-def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5):
+def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None):
     """Gradient comparison used by every parity test: rtol 1e-3 (BASELINE.json north_star)
     plus an absolute floor of atol_rel x the largest gradient magnitude in the whole model.
     The floor is needed because some gradients are pure cancellation noise in fp32 (e.g.
-    the bias of a conv whose outputs are all positive before BatchNorm: true gradient 0)."""
+    the bias of a conv whose outputs are all positive before BatchNorm: true gradient 0).
+
+    truth (optional): the same gradients from the oracle evaluated in float64.  An element that
+    misses the fp32 reference by more than the tolerance is still accepted when it is at least as
+    close to the float64 truth as a small multiple of the fp32 reference's OWN rounding error
+    (ill-conditioned sums over raw data of magnitude ~100: two fp32 evaluation orders differ)."""
     import torch
 
     assert set(got) == set(want), (sorted(set(got) ^ set(want)))
     gmax = max(float(v.abs().max()) for v in want.values())
     for k, v in want.items():
-        torch.testing.assert_close(got[k].detach().float().cpu(), v.float(), rtol=rtol, atol=atol_rel * gmax,
-                                   msg=lambda m, k=k: f"grad {k}: {m}")
+        a, v = got[k].detach().float().cpu(), v.float()
+        bad = (a - v).abs() > atol_rel * gmax + rtol * v.abs()
+        if bad.any() and truth is not None:
+            t = truth[k].double()
+            ref_err = (v.double() - t).abs()
+            bad &= (a.double() - t).abs() > 8 * ref_err + atol_rel * gmax
+        assert not bad.any(), (f"grad {k}: {int(bad.sum())}/{bad.numel()} elements off, max abs diff "
+                               f"{float((a - v).abs().max()):.4e} (allowed {atol_rel * gmax:.3e} + {rtol}*|ref|)")
 
 
 def assert_params_close(got, want, grads0, steps, lr, rtol=2e-4, atol=2e-5, noise_rel=2e-5):
@@ -86,3 +97,10 @@ def assert_params_close(got, want, grads0, steps, lr, rtol=2e-4, atol=2e-5, nois
         worst = float((a - v).abs().max())
         assert bad.float().mean() <= 0.01 and worst <= 2.5 * steps * lr + atol, \
             f"param {k}: {int(bad.sum())}/{bad.numel()} elements off, max diff {worst:.3e}"
+
+
+def truth64(family, sd, x, eps, **kw):
+    """Gradients of the oracle evaluated in float64 (see assert_grads_close)."""
+    from oracle import vae_oracle as O
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    return O.loss_and_grads(family, sd64, x.double(), eps.double(), **kw)["grads"]

@@ -7,7 +7,7 @@ conftest.assert_grads_close."""
 import pytest
 import torch
 
-from conftest import assert_grads_close, assert_params_close, load_golden, sub
+from conftest import assert_grads_close, assert_params_close, load_golden, sub, truth64
 from test_cpu_host import _build
 
 pytestmark = pytest.mark.gpu
@@ -43,7 +43,7 @@ def test_forward_loss_grads_match_reference(golden_case):
     close(loss, g["loss0"], atol=1e-2)
     loss.backward()
     got = {k: p.grad for k, p in m.named_parameters()}
-    assert_grads_close(got, sub(g, "grad/"))
+    assert_grads_close(got, sub(g, "grad/"), truth=truth64(family, sub(g, "sd/"), g["x"], g["eps0"], **kw))
     sd = m.state_dict()
     for k, v in sub(g, "sd1/").items():
         close(sd[k], v, atol=1e-5)
@@ -92,7 +92,7 @@ def test_fused_train_step_trajectory(golden_case, use_graph):
             close(st.output("x_rec"), g["out/x_rec"])
             got = {k: p.grad.clone() for k, p in m.named_parameters()}
             # p.grad aliases the fused gradient buffer of the LAST step: compare right after step 0
-            assert_grads_close(got, sub(g, "grad/"))
+            assert_grads_close(got, sub(g, "grad/"), truth=truth64(family, sub(g, "sd/"), g["x"], g["eps0"], **kw))
     assert abs(st.total.item() - total) <= 2e-3 * abs(total)
     assert_params_close(m.state_dict(), sub(g, "sd3/"), sub(g, "grad/"), steps=3, lr=1e-3)
 
@@ -142,7 +142,7 @@ def test_against_oracle_at_larger_batch(stem, family, kw, B):
     loss = _crit(family)(x_rec, _target(family, xd), mu, logvar)
     close(loss, ref["loss"], atol=1e-1)
     loss.backward()
-    assert_grads_close({k: p.grad for k, p in m.named_parameters()}, ref["grads"])
+    assert_grads_close({k: p.grad for k, p in m.named_parameters()}, ref["grads"], truth=truth64(family, sd, x, eps, **kw))
 
 
 def test_submodule_calls_and_reparam():

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvae_amd.so")
 # enums (include/vae_amd.h)
 OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
-F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE = 1, 2, 4, 8, 16
+F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
 MAX_CHUNKS, ELBO_BLOCKS = 64, 256
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
 
@@ -48,6 +48,7 @@ def lib():
     L.vae_check_device.argtypes = []
     L.vae_run_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp]
     L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
+    L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_elbo_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]
@@ -56,7 +57,7 @@ def lib():
     L.vae_graph_end.argtypes = [ctypes.POINTER(vp)]
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
-    for name in ("vae_check_device", "vae_run_forward", "vae_run_backward", "vae_elbo_forward", "vae_elbo_backward",
+    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_run_forward", "vae_run_backward", "vae_elbo_forward", "vae_elbo_backward",
                  "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end", "vae_graph_launch",
                  "vae_graph_destroy"):
         getattr(L, name).restype = i32
@@ -64,7 +65,7 @@ def lib():
     return L
 
 
-EXPORTS = ("vae_last_error", "vae_check_device", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
+EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
            "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 

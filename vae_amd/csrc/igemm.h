@@ -1,0 +1,539 @@
+// igemm.h - LDS-staged implicit-GEMM convolution kernels on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// One workgroup owns a chunk of SB consecutive samples.  It stages the chunk's input
+// activations ONCE into LDS (zero halo, with the producer's BatchNorm+ReLU or this layer's
+// gradient transform applied on the way in), builds the im2col offset table and the
+// [k][n] weight image in LDS, and then every 16-pixel x 16-channel output tile is a chain of
+// MFMAs whose A operand is gathered from the staged tile (pixel base + tap offset) and whose
+// B operand is the weight image.  Results go through an LDS output tile so that the global
+// store of the chunk is one contiguous, coalesced stream, and the per-channel sums that
+// BatchNorm needs (forward: sum, sum of squares; backward: sum g, sum g*xhat) are taken from
+// that tile in the same kernel ("virtual" BatchNorm: its output is never materialised).
+//
+//   igemm_gather_k : Conv forward, ConvT forward (per output-parity class), and both input
+//                    gradients (Conv dgrad = transposed gather, ConvT dgrad = conv gather).
+//   igemm_wgrad_k  : weight gradient (K = pixels), bias gradient taken while staging.
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { TR_PLAIN = 0, TR_BN = 1, TR_GRAD_BN = 2, TR_GRAD_ACT = 3 };
+enum { EP_PLAIN = 0, EP_BNGRAD = 1 };
+
+// How a [B][C][HW] tensor is read into LDS.
+//   TR_PLAIN    v = src[e]
+//   TR_BN       v = (src[e]-mean[c])*scale[c] + beta[c], then ReLU if relu   (coef = BN save block)
+//   TR_GRAD_BN  v = (a[c]*src[e] + b[c]*(src2[e]-mean[c]) + cc[c]) * act'(src2[e])   (src = g, src2 = y)
+//   TR_GRAD_ACT v = src[e] * act'(src2[e])
+struct TensorIn {
+    const float* src;
+    const float* src2;
+    const float* coef;  // BN save block: mean, rstd, scale, beta, a, b, c, spare (each C floats)
+    int mode, relu, act;
+    float slope;
+};
+
+__device__ __forceinline__ float tensor_in_value(const TensorIn& t, int64_t e, int c, int C) {
+    float v = t.src[e];
+    if (t.mode == TR_BN) {
+        v = fmaf(v - t.coef[c], t.coef[2 * C + c], t.coef[3 * C + c]);  // (y - mean) * scale + beta
+        if (t.relu) v = v > 0.f ? v : 0.f;
+    } else if (t.mode == TR_GRAD_BN) {
+        const float y = t.src2[e];
+        v = fmaf(t.coef[4 * C + c], v, fmaf(t.coef[5 * C + c], y - t.coef[c], t.coef[6 * C + c]));
+        v *= act_grad_from_out(y, t.act, t.slope);
+    } else if (t.mode == TR_GRAD_ACT) {
+        v *= act_grad_from_out(t.src2[e], t.act, t.slope);
+    }
+    return v;
+}
+
+struct FastDiv {  // exact n / d for n * d < 2^32
+    uint32_t mul, d;
+};
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d == 1 ? n : __umulhi(n, f.mul); }
+
+struct IgGeom {
+    int Cin, H, W;      // gathered tensor, per sample
+    int N, OH, OW;      // produced tensor
+    int KH, KW;
+    int si_h, si_w;     // input step per class pixel  (conv: stride, transposed: 1)
+    int so_h, so_w;     // output step per class pixel (conv: 1, transposed: stride)
+    int ph, pw;
+    int transposed;
+    int Hp, Wp, halo_h, halo_w;  // LDS image of one input channel: Hp x Wp with zero halo
+    int w_cstride, w_nstride;    // weight element (ci, n, kh, kw) at ci*w_cstride + n*w_nstride + kh*KW + kw
+    int Np;                      // N rounded up to 16
+    FastDiv d_HW, d_W, d_CHW;    // for staging decode
+};
+
+struct IgArgs {
+    IgGeom g;
+    TensorIn in;
+    const float* w;
+    const float* bias;
+    float* out;
+    int B, SB;
+    int act;
+    float slope;
+    // epilogue
+    int ep_mode;              // EP_PLAIN / EP_BNGRAD
+    const float* ep_y;        // EP_BNGRAD: producer output y_prev (same layout as out)
+    const float* ep_coef;     // EP_BNGRAD: producer BN save block
+    int ep_relu;
+    float* slab;              // per-block per-channel {pivot, s1, s2, count} (forward statistics) or
+                              // {s1, s2, -, -} (backward sums), or nullptr
+    // LDS carve (floats)
+    int lds_in, lds_w, lds_out, lds_tab;
+};
+
+// per-class tap enumeration (uniform scalar math, recomputed by every thread)
+struct IgClass {
+    int rh, rw, AH, AW, kh0, kw0, nkh, nkw, ntaps, Kc, KcPad;
+};
+__device__ __forceinline__ IgClass ig_class(const IgGeom& g, int cls) {
+    IgClass c;
+    c.rh = cls / g.so_w;
+    c.rw = cls % g.so_w;
+    c.AH = (g.OH - c.rh + g.so_h - 1) / g.so_h;
+    c.AW = (g.OW - c.rw + g.so_w - 1) / g.so_w;
+    if (g.transposed) {
+        c.kh0 = (c.rh + g.ph) % g.so_h;
+        c.kw0 = (c.rw + g.pw) % g.so_w;
+        c.nkh = c.kh0 < g.KH ? (g.KH - c.kh0 + g.so_h - 1) / g.so_h : 0;
+        c.nkw = c.kw0 < g.KW ? (g.KW - c.kw0 + g.so_w - 1) / g.so_w : 0;
+    } else {
+        c.kh0 = c.kw0 = 0;
+        c.nkh = g.KH;
+        c.nkw = g.KW;
+    }
+    c.ntaps = c.nkh * c.nkw;
+    c.Kc = g.Cin * c.ntaps;
+    c.KcPad = (c.Kc + 3) & ~3;
+    return c;
+}
+
+// Stage [sb][C][H][W] (global, contiguous) into the padded LDS image, applying the transform.
+// Optionally accumulates per-channel sums of the staged values into red[c] (LDS atomics).
+__device__ __forceinline__ void ig_stage(const TensorIn& t, float* lds, int64_t gbase, int sb, int C, int HW, int W,
+                                         int Hp, int Wp, int halo_h, int halo_w, FastDiv d_CHW, FastDiv d_HW,
+                                         FastDiv d_W, float* red) {
+    const uint32_t total = (uint32_t)sb * C * HW;
+    const int chw_p = C * Hp * Wp;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const uint32_t s = fdiv(e, d_CHW);
+        const uint32_t r = e - s * (uint32_t)(C * HW);
+        const uint32_t c = fdiv(r, d_HW);
+        const uint32_t pos = r - c * (uint32_t)HW;
+        const uint32_t ih = fdiv(pos, d_W);
+        const uint32_t iw = pos - ih * (uint32_t)W;
+        const float v = tensor_in_value(t, gbase + e, (int)c, C);
+        lds[s * chw_p + c * Hp * Wp + (ih + halo_h) * Wp + iw + halo_w] = v;
+        if (red != nullptr) atomicAdd(&red[c], v);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void igemm_gather_k(IgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const IgGeom& g = a.g;
+    float* lin = smem;
+    float* lw = lin + a.lds_in;
+    float* lout = lw + a.lds_w;
+    int* ktab = reinterpret_cast<int*>(lout + a.lds_out);
+    float* red = reinterpret_cast<float*>(ktab + a.lds_tab);  // [Np][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * a.SB;
+    const int sb = min(a.SB, a.B - s0);
+    const int HpWp = g.Hp * g.Wp, CinHpWp = g.Cin * HpWp;
+    const int ncls = g.so_h * g.so_w;
+    const int OHW = g.OH * g.OW;
+
+    // 1. clear the input image (halo must read as zero)
+    for (int i = tid; i < a.lds_in; i += 256) lin[i] = 0.f;
+    for (int i = tid; i < 2 * g.Np; i += 256) red[i] = 0.f;
+    // 2. per class: tap offset table and the [k][n] weight image
+    {
+        int toff = 0, woff = 0;
+        for (int cls = 0; cls < ncls; ++cls) {
+            const IgClass c = ig_class(g, cls);
+            for (int k = tid; k < c.KcPad; k += 256) {
+                int off = 0;  // k >= Kc: weight row is zero, any finite in-range operand will do
+                if (k < c.Kc) {
+                    const int ci = k / c.ntaps, ti = k - ci * c.ntaps;
+                    const int i_h = ti / c.nkw, i_w = ti - i_h * c.nkw;
+                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
+                    int ro, co;
+                    if (g.transposed) {
+                        ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
+                        co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
+                    } else {
+                        ro = kh;
+                        co = kw;
+                    }
+                    off = ci * HpWp + ro * g.Wp + co;
+                }
+                ktab[toff + k] = off;
+            }
+            const int nw = c.KcPad * g.Np;
+            for (int i = tid; i < nw; i += 256) {
+                const int k = i / g.Np, n = i - k * g.Np;
+                float v = 0.f;
+                if (k < c.Kc && n < g.N) {
+                    const int ci = k / c.ntaps, ti = k - ci * c.ntaps;
+                    const int i_h = ti / c.nkw, i_w = ti - i_h * c.nkw;
+                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
+                    v = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
+                }
+                lw[woff + i] = v;
+            }
+            toff += c.KcPad;
+            woff += nw;
+        }
+    }
+    __syncthreads();
+    // 3. stage the chunk's input
+    ig_stage(a.in, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
+             g.d_CHW, g.d_HW, g.d_W, nullptr);
+    __syncthreads();
+
+    // 4. output tiles: 16 pixels of one class x 16*NT channels
+    {
+        int toff = 0, woff = 0, tile_base = 0;
+        const int n_ntile = g.Np / 16;
+        for (int cls = 0; cls < ncls; ++cls) {
+            const IgClass c = ig_class(g, cls);
+            const int AHW = c.AH * c.AW;
+            const int P = sb * AHW;
+            const int ntile = (P + 15) >> 4;
+            // round-robin over waves, continuing across classes for balance
+            for (int t = (wid + 4 - (tile_base & 3)) & 3; t < ntile; t += 4) {
+                const int q = t * 16 + li;
+                const bool valid = q < P;
+                const int qq = valid ? q : 0;
+                const int s = qq / AHW, rem = qq - s * AHW;
+                const int ah = rem / c.AW, aw = rem - ah * c.AW;
+                const int pixbase = s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
+                const int outoff = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
+                for (int nc = 0; nc < n_ntile; nc += NT) {
+                    f32x4 acc[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const float* lwc = lw + woff + nc * 16 + li;
+                    for (int k4 = 0; k4 < c.KcPad; k4 += 4) {
+                        const int k = k4 + lk;
+                        const float av = lin[pixbase + ktab[toff + k]];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            if (nc + j < n_ntile)
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lwc[k * g.Np + j * 16], acc[j], 0, 0, 0);
+                    }
+                    // D: col (channel) = li, row (pixel) = lk*4 + r
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oo = __shfl(outoff, lk * 4 + r, 64);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int n = (nc + j) * 16 + li;
+                            if (oo >= 0 && n < g.N) {
+                                float v = acc[j][r] + (a.bias != nullptr ? a.bias[n] : 0.f);
+                                lout[oo + n * OHW] = act_apply(v, a.act, a.slope);
+                            }
+                        }
+                    }
+                }
+            }
+            tile_base += ntile;
+            toff += c.KcPad;
+            woff += c.KcPad * g.Np;
+        }
+    }
+    __syncthreads();
+
+    // 5. write the chunk out (contiguous in global memory) + per-channel sums
+    const int64_t obase = (int64_t)s0 * g.N * OHW;
+    const int total = sb * g.N * OHW;
+    if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
+        for (int e = tid; e < total; e += 256) a.out[obase + e] = lout[e];
+        return;
+    }
+    // row-wise: one wave per (sample, channel) row so that each row's sums reduce by shuffles
+    const int rows = sb * g.N;
+    for (int row = wid; row < rows; row += 4) {
+        const int n = row % g.N;
+        float s1 = 0.f, s2 = 0.f;
+        float pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
+        if (a.ep_mode == EP_BNGRAD) {
+            mean = a.ep_coef[n];
+            rstd = a.ep_coef[g.N + n];
+            sc = a.ep_coef[2 * g.N + n];
+            sh = a.ep_coef[3 * g.N + n];
+        } else {
+            pv = lout[n * OHW];  // block-local pivot: this channel's first value in the chunk
+        }
+        for (int i = lane; i < OHW; i += 64) {
+            float v = lout[row * OHW + i];
+            if (a.ep_mode == EP_BNGRAD) {
+                const float y = a.ep_y[obase + (int64_t)row * OHW + i];
+                if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
+                s1 += v;
+                s2 = fmaf(v, (y - mean) * rstd, s2);
+            } else {
+                const float d = v - pv;
+                s1 += d;
+                s2 = fmaf(d, d, s2);
+            }
+            a.out[obase + (int64_t)row * OHW + i] = v;
+        }
+        if (a.slab != nullptr) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {
+                atomicAdd(&red[2 * n], s1);
+                atomicAdd(&red[2 * n + 1], s2);
+            }
+        }
+    }
+    if (a.slab != nullptr) {
+        __syncthreads();
+        for (int n = tid; n < g.N; n += 256) {
+            float* sl = a.slab + ((int64_t)blockIdx.x * g.N + n) * 4;
+            if (a.ep_mode == EP_BNGRAD) {
+                sl[0] = red[2 * n];
+                sl[1] = red[2 * n + 1];
+            } else {
+                sl[0] = lout[n * OHW];
+                sl[1] = red[2 * n];
+                sl[2] = red[2 * n + 1];
+                sl[3] = (float)(sb * OHW);
+            }
+        }
+    }
+}
+
+// ---- weight gradient --------------------------------------------------------------------------
+// dw[m][c][kh][kw] += sum_{b,oh,ow} S[b,m,oh,ow] * G[b,c,oh*sh-ph+kh,ow*sw-pw+kw]
+//   Conv : S = d(pre-activation) [Cout], G = layer input [Cin];  ConvT: S = layer input, G = d(pre-act).
+// MFMA: A[m][k=pixel] from the S tile, B[k=pixel][n=(c,tap)] gathered from the padded G tile.
+// The 4 waves split the pixel range; each holds ALL (m,n) tiles (<= WG_MAXT), reduced through
+// LDS at the end, then one atomicAdd per element and block.
+#define WG_MAXT 20
+
+struct WgArgs {
+    TensorIn S, G;
+    float* dw;
+    float* dbias;     // bias gradient (sum of the d(pre-act) tensor per channel) or nullptr
+    int bias_from_S;  // 1: dbias from S (Conv), 0: from G (ConvT)
+    int B, SB;
+    int Sc, SH, SW;   // S: channels, small grid
+    int Gc, GH, GW;   // G: channels, big grid
+    int KH, KW, sh, sw, ph, pw;
+    int Hp, Wp;       // padded G image (halo = ph, pw low side)
+    int Mp, NKp;      // Sc and Gc*KH*KW rounded up to 16
+    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW;
+    int lds_S, lds_G, lds_tab;
+};
+
+__global__ __launch_bounds__(256) void igemm_wgrad_k(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lS = smem;                 // [sb][Sc][SHW]
+    float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]
+    int* ptab = reinterpret_cast<int*>(lG + a.lds_G);  // per pixel: packed (S offset, G base)
+    float* red = reinterpret_cast<float*>(ptab + a.lds_tab);  // [max(Sc,Gc)]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int s0 = blockIdx.x * a.SB;
+    const int sb = min(a.SB, a.B - s0);
+    const int SHW = a.SH * a.SW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW;
+    const int NK = a.Gc * KK;
+    const int P = sb * SHW;
+    const int Ppad = (P + 3) & ~3;
+
+    for (int i = tid; i < a.lds_G; i += 256) lG[i] = 0.f;
+    for (int i = tid; i < a.lds_S; i += 256) lS[i] = 0.f;
+    const int nred = a.bias_from_S ? a.Sc : a.Gc;
+    for (int i = tid; i < nred; i += 256) red[i] = 0.f;
+    // pixel table: q -> S offset (s*Sc*SHW + pix) and G base (s*Gc*HpWp + oh*sh*Wp + ow*sw)
+    for (int q = tid; q < Ppad; q += 256) {
+        int so = 0, gb = 0;  // padded pixels: operands are forced to zero at the read
+        if (q < P) {
+            const int s = q / SHW, pix = q - s * SHW;
+            const int oh = pix / a.SW, ow = pix - oh * a.SW;
+            so = s * a.Sc * SHW + pix;
+            gb = s * a.Gc * HpWp + oh * a.sh * a.Wp + ow * a.sw;
+        }
+        ptab[2 * q] = so;
+        ptab[2 * q + 1] = gb;
+    }
+    __syncthreads();
+    ig_stage(a.S, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W,
+             (a.dbias != nullptr && a.bias_from_S) ? red : nullptr);
+    ig_stage(a.G, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
+             a.dG_CHW, a.dG_HW, a.dG_W, (a.dbias != nullptr && !a.bias_from_S) ? red : nullptr);
+    __syncthreads();
+    if (a.dbias != nullptr)
+        for (int i = tid; i < nred; i += 256) atomicAdd(&a.dbias[i], red[i]);
+
+    const int MT = a.Mp / 16, NTt = a.NKp / 16, T = MT * NTt;
+    // per-lane constants: B column n = nt*16 + li -> tap offset in the G image (or the zero pad)
+    int koffN[WG_MAXT];
+    f32x4 acc[WG_MAXT];
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t) {
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        koffN[t] = 0;
+    }
+    bool nvalid[WG_MAXT];
+#pragma unroll
+    for (int nt = 0; nt < WG_MAXT; ++nt) {
+        nvalid[nt] = false;
+        if (nt < NTt) {
+            const int n = nt * 16 + li;
+            if (n < NK) {
+                const int c = n / KK, tap = n - c * KK;
+                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                koffN[nt] = c * HpWp + kh * a.Wp + kw;
+                nvalid[nt] = true;
+            }
+        }
+    }
+    // pixels: wave w takes steps w, w+4, ... (4 pixels per MFMA step)
+    for (int q4 = wid * 4; q4 < Ppad; q4 += 16) {
+        const int q = q4 + lk;
+        const int so = ptab[2 * q], gb = ptab[2 * q + 1];
+        float av[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) av[mt] = (mt < MT && mt * 16 + li < a.Sc && q < P) ? lS[so + (mt * 16 + li) * SHW] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < WG_MAXT; ++nt) {
+            if (nt < NTt) {
+                const float bv = (nvalid[nt] && q < P) ? lG[gb + koffN[nt]] : 0.f;
+                if (MT == 1) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[nt], 0, 0, 0);
+                else if (2 * nt + 1 < WG_MAXT) {
+                    acc[2 * nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[2 * nt], 0, 0, 0);
+                    acc[2 * nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv, acc[2 * nt + 1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // cross-wave reduction through LDS: waves add their tiles in turn into rbuf[T][4][64]
+    // (overlays the S/G tiles, which are dead now; the host sizes lds_S + lds_G >= T*256)
+    float* rbuf = smem;
+    for (int w = 0; w < 4; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int t = 0; t < WG_MAXT; ++t)
+                if (t < T) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = &rbuf[(t * 4 + r) * 64 + lane];
+                        *p = (w == 0 ? 0.f : *p) + acc[t][r];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < T * 256; i += 256) {
+        const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
+        int mt, nt;
+        if (MT == 1) { mt = 0; nt = t; }
+        else { nt = t >> 1; mt = t & 1; }
+        const int m = mt * 16 + (l >> 4) * 4 + r;  // D row
+        const int n = nt * 16 + (l & 15);          // D col
+        if (m < a.Sc && n < NK) atomicAdd(&a.dw[(int64_t)m * NK + n], rbuf[i]);
+    }
+}
+
+// ---- virtual BatchNorm finalize ------------------------------------------------------------
+// One wave per channel.  forward: every block left {pivot_b, sum(y-p_b), sum((y-p_b)^2), n_b}; each is
+// turned into (n, mean, M2) and merged with Chan's parallel-variance formula, lanes first striding
+// over the blocks and then in a fixed butterfly, so the result is deterministic and does not lose
+// precision when |mean| >> std.  Writes save = {mean, rstd, scale, beta} and the running stats.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float tot = n + nb;
+    if (tot > 0.f) {
+        const float delta = mb - mean;
+        const float f = nb / tot;
+        mean = fmaf(delta, f, mean);
+        m2 += m2b + delta * delta * n * f;
+    }
+    n = tot;
+}
+__global__ __launch_bounds__(64) void bnv_finalize_fwd_k(const float* __restrict__ slab, int nblocks,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ save,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar, int C,
+                                                         float eps, float momentum, int training) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float mean, var;
+    if (training) {
+        float n = 0.f, mu = 0.f, m2 = 0.f;
+        for (int k = lane; k < nblocks; k += 64) {
+            const float* sl = slab + ((int64_t)k * C + c) * 4;
+            const float nb = sl[3];
+            if (nb > 0.f) {
+                const float d = sl[1] / nb;
+                chan_merge(n, mu, m2, nb, sl[0] + d, fmaxf(sl[2] - sl[1] * d, 0.f));
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float nb = __shfl_xor(n, off, 64), mb = __shfl_xor(mu, off, 64), m2b = __shfl_xor(m2, off, 64);
+            // merge in a fixed (lower lane first) order so both partners compute identical results
+            if (lane & off) {
+                float tn = nb, tm = mb, t2 = m2b;
+                chan_merge(tn, tm, t2, n, mu, m2);
+                n = tn; mu = tm; m2 = t2;
+            } else {
+                chan_merge(n, mu, m2, nb, mb, m2b);
+            }
+        }
+        mean = mu;
+        var = n > 0.f ? m2 / n : 0.f;
+        if (lane == 0) {
+            const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    if (lane == 0) {
+        const float rstd = rsqrtf(var + eps);
+        save[c] = mean;
+        save[C + c] = rstd;
+        save[2 * C + c] = gamma[c] * rstd;
+        save[3 * C + c] = beta[c];
+    }
+}
+// backward: slab of {sum g, sum g*xhat} -> dgamma, dbeta and (a, b, c) of dy = a*g + b*(y-mean) + c
+__global__ __launch_bounds__(64) void bnv_finalize_bwd_k(const float* __restrict__ slab, int nblocks,
+                                                         float* __restrict__ save, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int C, int64_t n) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < nblocks; k += 64) {
+        s1 += slab[((int64_t)k * C + c) * 4];
+        s2 += slab[((int64_t)k * C + c) * 4 + 1];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+    if (lane == 0) {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+        const float m1 = s1 / (float)n, m2 = s2 / (float)n;
+        const float rstd = save[C + c], sc = save[2 * C + c];
+        save[4 * C + c] = sc;  // dy = sc*(g - m1 - xhat*m2)
+        save[5 * C + c] = -sc * m2 * rstd;
+        save[6 * C + c] = -sc * m1;
+    }
+}

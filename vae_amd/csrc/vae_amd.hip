@@ -13,6 +13,7 @@
 #include "conv.h"
 #include "elem.h"
 #include "gemm.h"
+#include "igemm.h"
 
 static thread_local char g_err[512] = "";
 void vae_set_error(const char* fmt, ...) {
@@ -40,6 +41,7 @@ struct Ctx {
     int n_bases;
     int B;
     hipStream_t s;
+    mutable int last_blocks;  // blocks that wrote the per-channel slab consumed by the next BN finalize
 };
 static inline int ref_space(int64_t r) { return (int)(r >> 56); }
 static inline int64_t ref_off(int64_t r) { return r & (((int64_t)1 << 56) - 1); }
@@ -234,6 +236,321 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     return rc;
 }
 
+
+// ---- fused implicit-GEMM conv path (igemm.h) ------------------------------------------------
+#define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two workgroups per CU
+
+static FastDiv mk_fdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.mul = d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0;
+    return f;
+}
+
+// Geometry of a gather that reads (Cin,H,W) and produces (N,OH,OW).  transposed: ConvT forward /
+// Conv dgrad; else Conv forward / ConvT dgrad.  wform_conv: weight element (ci,n) at
+// n*Cin*KK + ci*KK (Conv layout seen from this gather), else at ci*N*KK + n*KK.
+static IgGeom make_geom(int transposed, int Cin, int H, int W, int N, int OH, int OW, int KH, int KW, int sh, int sw,
+                        int ph, int pw, int wform_conv) {
+    IgGeom g;
+    g.Cin = Cin; g.H = H; g.W = W; g.N = N; g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW;
+    g.ph = ph; g.pw = pw; g.transposed = transposed;
+    const int KK = KH * KW;
+    if (!transposed) {
+        g.si_h = sh; g.si_w = sw; g.so_h = 1; g.so_w = 1;
+        g.halo_h = ph; g.halo_w = pw;
+        g.Hp = (OH - 1) * sh + KH; if (g.Hp < H + ph) g.Hp = H + ph;
+        g.Wp = (OW - 1) * sw + KW; if (g.Wp < W + pw) g.Wp = W + pw;
+    } else {
+        g.si_h = 1; g.si_w = 1; g.so_h = sh; g.so_w = sw;
+        // enumerate classes: row offset dh = (rh + ph - kh)/sh over valid taps, rows a + dh, a < AH
+        int lo_h = 0, hi_h = H - 1, lo_w = 0, hi_w = W - 1;
+        for (int rh = 0; rh < sh; ++rh) {
+            const int AH = (OH - rh + sh - 1) / sh;
+            for (int kh = (rh + ph) % sh; kh < KH; kh += sh) {
+                const int dh = (rh + ph - kh) / sh;
+                if (dh < lo_h) lo_h = dh;
+                if (AH - 1 + dh > hi_h) hi_h = AH - 1 + dh;
+            }
+        }
+        for (int rw = 0; rw < sw; ++rw) {
+            const int AW = (OW - rw + sw - 1) / sw;
+            for (int kw = (rw + pw) % sw; kw < KW; kw += sw) {
+                const int dw = (rw + pw - kw) / sw;
+                if (dw < lo_w) lo_w = dw;
+                if (AW - 1 + dw > hi_w) hi_w = AW - 1 + dw;
+            }
+        }
+        g.halo_h = -lo_h; g.halo_w = -lo_w;
+        g.Hp = hi_h - lo_h + 1; g.Wp = hi_w - lo_w + 1;
+    }
+    if (wform_conv) { g.w_cstride = KK; g.w_nstride = Cin * KK; }
+    else { g.w_cstride = N * KK; g.w_nstride = KK; }
+    g.Np = (N + 15) & ~15;
+    g.d_HW = mk_fdiv((uint32_t)(H * W));
+    g.d_W = mk_fdiv((uint32_t)W);
+    g.d_CHW = mk_fdiv((uint32_t)(Cin * H * W));
+    return g;
+}
+
+struct IgPlan {
+    int SB, lds_in, lds_w, lds_out, lds_tab, total;
+};
+// LDS need of the gather kernel for SB samples per block; picks SB for batch B (0 if it cannot fit)
+static IgPlan plan_gather(const IgGeom& g, int B) {
+    IgPlan p;
+    int wsum = 0, tsum = 0;
+    const int ncls = g.so_h * g.so_w;
+    for (int cls = 0; cls < ncls; ++cls) {
+        int nkh, nkw;
+        if (g.transposed) {
+            const int rh = cls / g.so_w, rw = cls % g.so_w;
+            const int kh0 = (rh + g.ph) % g.so_h, kw0 = (rw + g.pw) % g.so_w;
+            nkh = kh0 < g.KH ? (g.KH - kh0 + g.so_h - 1) / g.so_h : 0;
+            nkw = kw0 < g.KW ? (g.KW - kw0 + g.so_w - 1) / g.so_w : 0;
+        } else { nkh = g.KH; nkw = g.KW; }
+        const int KcPad = (g.Cin * nkh * nkw + 3) & ~3;
+        wsum += KcPad * g.Np;
+        tsum += KcPad;
+    }
+    const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW;
+    const int fixed = wsum + tsum + 2 * g.Np + 8;
+    int fit = (IG_LDS_BUDGET_FLOATS - fixed) / (per_in + per_out);
+    if (fit > 64) fit = 64;
+    int sb = 0;
+    if (fit >= 1) {
+        sb = (B + 1023) / 1024;                       // >= ~1024 blocks when the batch allows
+        while (sb < fit && sb * per_in < wsum) ++sb;  // amortise the per-block weight image
+        if (sb > fit) sb = fit;
+        if (sb < 1) sb = 1;
+        if (sb > B) sb = B;
+    }
+    p.SB = sb;
+    p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * per_out; p.lds_tab = tsum;
+    p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + 2 * g.Np;
+    if ((uint64_t)(p.lds_in > p.lds_out ? p.lds_in : p.lds_out) * (uint64_t)(g.Cin * g.H * g.W + 1) >= ((uint64_t)1 << 32)) p.SB = 0;
+    return p;
+}
+
+struct WgPlan {
+    int SB, lds_S, lds_G, lds_tab, total, Hp, Wp, Mp, NKp;
+};
+static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, int KH, int KW, int sh, int sw, int ph,
+                         int pw) {
+    WgPlan p;
+    p.Hp = (SH - 1) * sh + KH; if (p.Hp < GH + ph) p.Hp = GH + ph;
+    p.Wp = (SW - 1) * sw + KW; if (p.Wp < GW + pw) p.Wp = GW + pw;
+    p.Mp = (Sc + 15) & ~15;
+    p.NKp = (Gc * KH * KW + 15) & ~15;
+    const int T = (p.Mp / 16) * (p.NKp / 16);
+    const int per_S = Sc * SH * SW, per_G = Gc * p.Hp * p.Wp, per_tab = 2 * SH * SW;
+    const int nred = Sc > Gc ? Sc : Gc;
+    int fit = (IG_LDS_BUDGET_FLOATS - nred - 16) / (per_S + per_G + per_tab);
+    if (fit > 64) fit = 64;
+    int sb = 0;
+    if (fit >= 1 && p.Mp <= 32 && T <= WG_MAXT) {
+        sb = (B + 1023) / 1024;
+        while (sb < fit && sb * (per_S + per_G) < T * 256) ++sb;  // room for the cross-wave reduction image
+        if (sb > fit) sb = fit;
+        if (sb < 1) sb = 1;
+        if (sb > B) sb = B;
+        if (sb * (per_S + per_G) < T * 256 && (B >= fit)) sb = 0;
+    }
+    p.SB = sb;
+    p.lds_S = sb * per_S; p.lds_G = sb * per_G;
+    if (p.lds_S + p.lds_G < T * 256) p.lds_G = T * 256 - p.lds_S;  // tiny batches: pad the G region
+    p.lds_tab = ((sb * SH * SW + 3) & ~3) * 2;
+    p.total = p.lds_S + p.lds_G + p.lds_tab + nred + 8;
+    if (p.total > IG_LDS_BUDGET_FLOATS) p.SB = 0;
+    return p;
+}
+
+static int conv_igemm_fits(const vae_op& op, int B) {
+    const ConvGeom g = geom_of(op);
+    const int T = op.kind == VAE_OP_CONVT;
+    // forward gather, input-gradient gather, weight gradient
+    const IgGeom f = make_geom(T, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, !T);
+    const IgGeom d = make_geom(!T, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, T);
+    const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
+                       : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+    return plan_gather(f, B).SB >= 1 && plan_gather(d, B).SB >= 1 && w.SB >= 1 && g.sh <= 2 && g.sw <= 2;
+}
+
+extern "C" int vae_conv_fused_ok(const vae_op* op, int B) {
+    if (op == nullptr || (op->kind != VAE_OP_CONV && op->kind != VAE_OP_CONVT) || B < 1) return 0;
+    if (check_geom(*op) != VAE_OK) return 0;
+    return conv_igemm_fits(*op, B);
+}
+
+static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
+    const IgPlan p = plan_gather(a.g, c.B);
+    if (p.SB < 1) VAE_FAIL(VAE_EINVAL, "%s: layer does not fit the fused conv kernel's LDS budget", what);
+    a.B = c.B; a.SB = p.SB;
+    a.lds_in = p.lds_in; a.lds_w = p.lds_w; a.lds_out = p.lds_out; a.lds_tab = p.lds_tab;
+    const int grid = (c.B + p.SB - 1) / p.SB;
+    const size_t bytes = (size_t)p.total * sizeof(float);
+    if (a.g.Np > 16)
+        hipLaunchKernelGGL(igemm_gather_k<2>, dim3(grid), dim3(256), bytes, c.s, a);
+    else
+        hipLaunchKernelGGL(igemm_gather_k<1>, dim3(grid), dim3(256), bytes, c.s, a);
+    VAE_LAUNCH_CHECK(what);
+    if (a.slab != nullptr) c.last_blocks = grid;
+    return VAE_OK;
+}
+
+static TensorIn tensor_plain(const float* p) {
+    TensorIn t;
+    t.src = p; t.src2 = nullptr; t.coef = nullptr; t.mode = TR_PLAIN; t.relu = 0; t.act = VAE_ACT_NONE; t.slope = 0.f;
+    return t;
+}
+
+// scratch must hold grid * 2 * C floats for the slab
+static int slab_ok(const Ctx& c, int64_t ref, int blocks, int C) {
+    bool ok = true;
+    resolve(c, ref, (int64_t)blocks * 4 * C, "conv.slab", &ok);
+    return ok ? VAE_OK : VAE_EINVAL;
+}
+
+static int conv_forward_fused(const Ctx& c, const vae_op& op, int training) {
+    int rc = check_geom(op);
+    if (rc) return rc;
+    const ConvGeom g = geom_of(op);
+    const int T = op.kind == VAE_OP_CONVT;
+    bool ok = true;
+    const int64_t nin = (int64_t)c.B * g.Cin * g.H * g.W, nout = (int64_t)c.B * g.Cout * g.OH * g.OW;
+    const int64_t nw = (int64_t)g.Cin * g.Cout * g.KH * g.KW;
+    IgArgs a;
+    a.g = make_geom(T, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, !T);
+    a.in = tensor_plain(resolve(c, op.r[0], nin, "conv.in", &ok));
+    if (op.r[7] >= 0) {
+        a.in.mode = TR_BN;
+        a.in.coef = resolve(c, op.r[7], (int64_t)8 * g.Cin, "conv.in_bn", &ok);
+        a.in.relu = (op.flags & VAE_F_IN_RELU) ? 1 : 0;
+    }
+    a.out = resolve(c, op.r[1], nout, "conv.out", &ok);
+    a.w = resolve(c, op.r[4], nw, "conv.w", &ok);
+    a.bias = resolve_opt(c, op.r[5], g.Cout, "conv.b", &ok);
+    a.act = op.act; a.slope = op.f[0];
+    a.ep_mode = EP_PLAIN; a.ep_y = nullptr; a.ep_coef = nullptr; a.ep_relu = 0;
+    a.slab = nullptr;
+    if (op.r[8] >= 0 && training) {
+        const IgPlan p = plan_gather(a.g, c.B);
+        if (p.SB >= 1 && slab_ok(c, op.r[6], (c.B + p.SB - 1) / p.SB, g.Cout)) return VAE_EINVAL;
+        a.slab = resolve(c, op.r[6], 4 * g.Cout, "conv.slab", &ok);
+    }
+    if (!ok) return VAE_EINVAL;
+    return launch_igemm_gather(c, a, "igemm_gather_k(fwd)");
+}
+
+static int conv_backward_fused(const Ctx& c, const vae_op& op) {
+    int rc = check_geom(op);
+    if (rc) return rc;
+    const ConvGeom g = geom_of(op);
+    const int T = op.kind == VAE_OP_CONVT;
+    bool ok = true;
+    const int64_t nin = (int64_t)c.B * g.Cin * g.H * g.W, nout = (int64_t)c.B * g.Cout * g.OH * g.OW;
+    const int64_t nw = (int64_t)g.Cin * g.Cout * g.KH * g.KW;
+    // layer input as the forward saw it
+    TensorIn tin = tensor_plain(resolve(c, op.r[0], nin, "conv.in", &ok));
+    if (op.r[7] >= 0) {
+        tin.mode = TR_BN;
+        tin.coef = resolve(c, op.r[7], (int64_t)8 * g.Cin, "conv.in_bn", &ok);
+        tin.relu = (op.flags & VAE_F_IN_RELU) ? 1 : 0;
+    }
+    // d(pre-activation) of this layer, computed on load from the stored gradient and the output
+    TensorIn tg = tensor_plain(resolve(c, op.r[3], nout, "conv.dout", &ok));
+    tg.src2 = resolve(c, op.r[1], nout, "conv.out", &ok);
+    tg.act = op.act; tg.slope = op.f[0];
+    if (op.r[8] >= 0) {
+        tg.mode = TR_GRAD_BN;
+        tg.coef = resolve(c, op.r[8], (int64_t)8 * g.Cout, "conv.out_bn", &ok);
+    } else if (op.act != VAE_ACT_NONE) {
+        tg.mode = TR_GRAD_ACT;
+    }
+    const float* w = resolve(c, op.r[4], nw, "conv.w", &ok);
+    float* dw = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), nw, "conv.dw", &ok);
+    float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), g.Cout, "conv.db", &ok);
+    float* dx = resolve_opt(c, op.r[2], nin, "conv.din", &ok);
+    if (!ok) return VAE_EINVAL;
+
+    // 1) weight (+bias) gradient
+    WgArgs wa;
+    WgPlan wp;
+    if (!T) {
+        wp = plan_wgrad(c.B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+        wa.S = tg; wa.G = tin; wa.bias_from_S = 1;
+        wa.Sc = g.Cout; wa.SH = g.OH; wa.SW = g.OW; wa.Gc = g.Cin; wa.GH = g.H; wa.GW = g.W;
+    } else {
+        wp = plan_wgrad(c.B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+        wa.S = tin; wa.G = tg; wa.bias_from_S = 0;
+        wa.Sc = g.Cin; wa.SH = g.H; wa.SW = g.W; wa.Gc = g.Cout; wa.GH = g.OH; wa.GW = g.OW;
+    }
+    if (wp.SB < 1) VAE_FAIL(VAE_EINVAL, "conv wgrad: layer does not fit the fused kernel");
+    wa.dw = dw; wa.dbias = db; wa.B = c.B; wa.SB = wp.SB;
+    wa.KH = g.KH; wa.KW = g.KW; wa.sh = g.sh; wa.sw = g.sw; wa.ph = g.ph; wa.pw = g.pw;
+    wa.Hp = wp.Hp; wa.Wp = wp.Wp; wa.Mp = wp.Mp; wa.NKp = wp.NKp;
+    wa.dS_HW = mk_fdiv(wa.SH * wa.SW); wa.dS_W = mk_fdiv(wa.SW); wa.dS_CHW = mk_fdiv(wa.Sc * wa.SH * wa.SW);
+    wa.dG_HW = mk_fdiv(wa.GH * wa.GW); wa.dG_W = mk_fdiv(wa.GW); wa.dG_CHW = mk_fdiv(wa.Gc * wa.GH * wa.GW);
+    wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
+    hipLaunchKernelGGL(igemm_wgrad_k, dim3((c.B + wp.SB - 1) / wp.SB), dim3(256), (size_t)wp.total * sizeof(float), c.s,
+                       wa);
+    VAE_LAUNCH_CHECK("igemm_wgrad_k");
+
+    // 2) input gradient
+    if (dx == nullptr) return VAE_OK;
+    IgArgs a;
+    a.g = make_geom(!T, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, T);
+    a.in = tg;
+    a.out = dx; a.w = w; a.bias = nullptr; a.act = VAE_ACT_NONE; a.slope = 0.f;
+    a.ep_mode = EP_PLAIN; a.ep_y = nullptr; a.ep_coef = nullptr; a.ep_relu = 0; a.slab = nullptr;
+    if (op.r[7] >= 0) {  // the producer's BatchNorm is virtual: mask by its ReLU and take its backward sums here
+        a.ep_mode = EP_BNGRAD;
+        a.ep_y = tin.src; a.ep_coef = tin.coef; a.ep_relu = tin.relu;
+        const IgPlan p = plan_gather(a.g, c.B);
+        if (p.SB >= 1 && slab_ok(c, op.r[6], (c.B + p.SB - 1) / p.SB, g.Cin)) return VAE_EINVAL;
+        a.slab = resolve(c, op.r[6], 4 * g.Cin, "conv.slab", &ok);
+        if (!ok) return VAE_EINVAL;
+    }
+    return launch_igemm_gather(c, a, "igemm_gather_k(dgrad)");
+}
+
+static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
+    const int C = op.d[0], HW = op.d[1];
+    if (C < 1 || HW < 1) VAE_FAIL(VAE_EINVAL, "bn: bad shape C=%d HW=%d", C, HW);
+    if (training && (int64_t)c.B * HW < 2) VAE_FAIL(VAE_EINVAL, "bn: training needs more than 1 value per channel");
+    bool ok = true;
+    const float* gamma = resolve(c, op.r[4], C, "bn.gamma", &ok);
+    const float* beta = resolve(c, op.r[5], C, "bn.beta", &ok);
+    float* save = resolve(c, op.r[6], (int64_t)8 * C, "bn.save", &ok);
+    float* rm = resolve(c, op.r[7], C, "bn.running_mean", &ok);
+    float* rv = resolve(c, op.r[8], C, "bn.running_var", &ok);
+    const int nblocks = training ? c.last_blocks : 0;
+    const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
+    if (!ok) return VAE_EINVAL;
+    if (training && nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no producer statistics");
+    hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(64), 0, c.s, slab, nblocks, gamma, beta, save, rm, rv, C,
+                       op.f[0], op.f[1], training);
+    VAE_LAUNCH_CHECK("bnv_finalize_fwd_k");
+    c.last_blocks = 0;
+    return VAE_OK;
+}
+static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
+    const int C = op.d[0], HW = op.d[1];
+    bool ok = true;
+    float* dgamma = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), C, "bn.dgamma", &ok);
+    float* dbeta = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), C, "bn.dbeta", &ok);
+    float* save = resolve(c, op.r[6], (int64_t)8 * C, "bn.save", &ok);
+    const int nblocks = c.last_blocks;
+    const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
+    if (!ok) return VAE_EINVAL;
+    if (nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no consumer gradient statistics");
+    hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(64), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
+                       (int64_t)c.B * HW);
+    VAE_LAUNCH_CHECK("bnv_finalize_bwd_k");
+    c.last_blocks = 0;
+    return VAE_OK;
+}
+
 // ---- batch norm -----------------------------------------------------------------------------
 static int bn_forward(const Ctx& c, const vae_op& op, int training) {
     const int C = op.d[0], HW = op.d[1];
@@ -246,7 +563,7 @@ static int bn_forward(const Ctx& c, const vae_op& op, int training) {
     float* y = resolve(c, op.r[1], total, "bn.out", &ok);
     const float* gamma = resolve(c, op.r[4], C, "bn.gamma", &ok);
     const float* beta = resolve(c, op.r[5], C, "bn.beta", &ok);
-    float* save = resolve(c, op.r[6], (int64_t)4 * C, "bn.save", &ok);
+    float* save = resolve(c, op.r[6], (int64_t)8 * C, "bn.save", &ok);
     float* rm = resolve(c, op.r[7], C, "bn.running_mean", &ok);
     float* rv = resolve(c, op.r[8], C, "bn.running_var", &ok);
     float* part = resolve(c, op.r[9], (int64_t)2 * C * VAE_MAX_CHUNKS, "bn.partials", &ok);
@@ -281,7 +598,7 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
     const float* gamma = resolve(c, op.r[4], C, "bn.gamma", &ok);
     float* dgamma = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), C, "bn.dgamma", &ok);
     float* dbeta = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), C, "bn.dbeta", &ok);
-    float* save = resolve(c, op.r[6], (int64_t)4 * C, "bn.save", &ok);
+    float* save = resolve(c, op.r[6], (int64_t)8 * C, "bn.save", &ok);
     float* part = resolve(c, op.r[9], (int64_t)2 * C * VAE_MAX_CHUNKS, "bn.partials", &ok);
     if (!ok) return VAE_EINVAL;
     int bchunk, nchunks;
@@ -498,6 +815,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     if (n_bases < 4 || n_bases > 128) VAE_FAIL(VAE_EINVAL, "n_bases=%d out of range", n_bases);
     if (B < 1 || B > (1 << 24)) VAE_FAIL(VAE_EINVAL, "batch %d out of range", B);
     c->bases = bases; c->sizes = sizes; c->n_bases = n_bases; c->B = B; c->s = (hipStream_t)stream;
+    c->last_blocks = 0;
     return VAE_OK;
 }
 
@@ -509,8 +827,12 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
         const vae_op& op = ops[i];
         switch (op.kind) {
             case VAE_OP_CONV:
-            case VAE_OP_CONVT: rc = conv_forward(c, op); break;
-            case VAE_OP_BN: rc = bn_forward(c, op, training); break;
+            case VAE_OP_CONVT:
+                rc = (op.flags & VAE_F_FUSED) ? conv_forward_fused(c, op, training) : conv_forward(c, op);
+                break;
+            case VAE_OP_BN:
+                rc = (op.flags & VAE_F_FUSED) ? bn_virtual_forward(c, op, training) : bn_forward(c, op, training);
+                break;
             case VAE_OP_LINEAR: rc = linear_forward(c, op); break;
             case VAE_OP_REPARAM: rc = reparam_forward(c, op); break;
             case VAE_OP_SLICE0: rc = slice0_forward(c, op); break;
@@ -533,8 +855,8 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
         const vae_op& op = ops[i];
         switch (op.kind) {
             case VAE_OP_CONV:
-            case VAE_OP_CONVT: rc = conv_backward(c, op); break;
-            case VAE_OP_BN: rc = bn_backward(c, op); break;
+            case VAE_OP_CONVT: rc = (op.flags & VAE_F_FUSED) ? conv_backward_fused(c, op) : conv_backward(c, op); break;
+            case VAE_OP_BN: rc = (op.flags & VAE_F_FUSED) ? bn_virtual_backward(c, op) : bn_backward(c, op); break;
             case VAE_OP_LINEAR: rc = linear_backward(c, op); break;
             case VAE_OP_REPARAM: rc = reparam_backward(c, op); break;
             case VAE_OP_SLICE0: rc = slice0_backward(c, op); break;

@@ -8,6 +8,7 @@ Address spaces: 0 WORK (activations, activation grads, scratch), 1 PARAM (flat p
 2 GRAD (flat parameter grads), 3 STATE (BatchNorm running statistics), 4.. one per program input.
 """
 import ctypes
+import os
 
 import torch
 
@@ -119,7 +120,7 @@ class ProgramBuilder:
         """bn: holder with .weight .bias .running_mean .running_var"""
         assert x.n == C * HW and x.ld == x.n
         y = self.act(C * HW)
-        save = self.fixed(4 * C)
+        save = self.fixed(8 * C)
         op = self._op(L.OP_BN, flags=L.F_BN_RELU if relu else 0,
                       r=(x.ref, y.ref, x.gref, y.gref, self.param(bn.weight), self.param(bn.bias), save,
                          self.state(bn.running_mean), self.state(bn.running_var)),
@@ -164,7 +165,38 @@ class ProgramBuilder:
         return out
 
     # -- finish ---------------------------------------------------------------------------
+    def _fuse(self):
+        """Graph rewrite: Conv/ConvT ops that fit the LDS-staged MFMA kernels get VAE_F_FUSED, and a
+        BatchNorm that sits between two such ops becomes virtual (never materialised): the producer's
+        epilogue takes its statistics, the consumer normalises (+ReLU) on load, and the backward pass
+        is folded into the same kernels (include/vae_amd.h, VAE_F_FUSED)."""
+        lib = L.lib()
+        convs = (L.OP_CONV, L.OP_CONVT)
+        for op in self.ops:
+            if op.kind in convs and lib.vae_conv_fused_ok(ctypes.byref(op), self.B):
+                op.flags |= L.F_FUSED
+                self.scratch_need = max(self.scratch_need, 4 * max(op.d[0], op.d[3]) * self.B)
+        out_refs = {buf.ref for buf, _ in self.outputs.values()}
+        for bn in self.ops:
+            if bn.kind != L.OP_BN or bn.r[1] in out_refs:
+                continue
+            prod = [o for o in self.ops if o.kind in convs and o.r[1] == bn.r[0]]
+            cons = [o for o in self.ops if o is not bn and o.r[0] == bn.r[1]]
+            if len(prod) != 1 or len(cons) != 1 or cons[0].kind not in convs:
+                continue
+            p, c = prod[0], cons[0]
+            if not (p.flags & L.F_FUSED and c.flags & L.F_FUSED):
+                continue
+            c.r[0], c.r[2], c.r[7] = bn.r[0], bn.r[2], bn.r[6]
+            if bn.flags & L.F_BN_RELU:
+                c.flags |= L.F_IN_RELU
+            p.r[8], p.r[9] = bn.r[6], bn.r[7]
+            bn.flags |= L.F_FUSED
+            bn.r[1] = bn.r[3] = -1
+
     def build(self):
+        if os.environ.get("VAE_AMD_UNFUSED", "0") != "1":
+            self._fuse()
         scratch = self.fixed(self.scratch_need)  # shared: ops run back to back on one stream
         for op, slot in self._scratch_ops:
             op.r[slot] = scratch
