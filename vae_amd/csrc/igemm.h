@@ -68,13 +68,20 @@ struct IgGeom {
     FastDiv d_HW, d_W, d_CHW;    // for staging decode
 };
 
+// One output-parity class (transposed gathers have so_h*so_w of them, plain convs one): which taps
+// contribute and where its tap table / weight image start in LDS.  Filled on the host.
+struct IgClass {
+    int rh, rw, AH, AW, kh0, kw0, nkh, nkw, ntaps, Kc, KcPad, toff, woff;
+    FastDiv d_ntaps, d_nkw, d_AHW, d_AW;
+};
+
 struct IgArgs {
     IgGeom g;
     TensorIn in;
     const float* w;
     const float* bias;
     float* out;
-    int B, SB;
+    int B, SB;  // SB consecutive samples form one chunk; workgroups loop over chunks
     int act;
     float slope;
     // epilogue
@@ -86,56 +93,68 @@ struct IgArgs {
                               // {s1, s2, -, -} (backward sums), or nullptr
     // LDS carve (floats)
     int lds_in, lds_w, lds_out, lds_tab;
+    int ncls, nchunks;
+    FastDiv d_N, d_ntile;  // by N and by Np/16
+    IgClass cls[4];
 };
 
-// per-class tap enumeration (uniform scalar math, recomputed by every thread)
-struct IgClass {
-    int rh, rw, AH, AW, kh0, kw0, nkh, nkw, ntaps, Kc, KcPad;
-};
-__device__ __forceinline__ IgClass ig_class(const IgGeom& g, int cls) {
-    IgClass c;
-    c.rh = cls / g.so_w;
-    c.rw = cls % g.so_w;
-    c.AH = (g.OH - c.rh + g.so_h - 1) / g.so_h;
-    c.AW = (g.OW - c.rw + g.so_w - 1) / g.so_w;
-    if (g.transposed) {
-        c.kh0 = (c.rh + g.ph) % g.so_h;
-        c.kw0 = (c.rw + g.pw) % g.so_w;
-        c.nkh = c.kh0 < g.KH ? (g.KH - c.kh0 + g.so_h - 1) / g.so_h : 0;
-        c.nkw = c.kw0 < g.KW ? (g.KW - c.kw0 + g.so_w - 1) / g.so_w : 0;
-    } else {
-        c.kh0 = c.kw0 = 0;
-        c.nkh = g.KH;
-        c.nkw = g.KW;
-    }
-    c.ntaps = c.nkh * c.nkw;
-    c.Kc = g.Cin * c.ntaps;
-    c.KcPad = (c.Kc + 3) & ~3;
-    return c;
-}
+#define IG_THREADS 512
+#define IG_WAVES (IG_THREADS / 64)
 
 // Stage [sb][C][H][W] (global, contiguous) into the padded LDS image, applying the transform.
-// Optionally accumulates per-channel sums of the staged values into red[c] (LDS atomics).
+// Optionally accumulates per-channel sums of the staged values into red[c]: lanes hold consecutive
+// elements, so equal channels form contiguous runs; a segmented shuffle reduction leaves each run's
+// sum in its first lane, which issues the only LDS atomic of the run.
 __device__ __forceinline__ void ig_stage(const TensorIn& t, float* lds, int64_t gbase, int sb, int C, int HW, int W,
                                          int Hp, int Wp, int halo_h, int halo_w, FastDiv d_CHW, FastDiv d_HW,
                                          FastDiv d_W, float* red) {
     const uint32_t total = (uint32_t)sb * C * HW;
     const int chw_p = C * Hp * Wp;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-        const uint32_t s = fdiv(e, d_CHW);
-        const uint32_t r = e - s * (uint32_t)(C * HW);
-        const uint32_t c = fdiv(r, d_HW);
-        const uint32_t pos = r - c * (uint32_t)HW;
-        const uint32_t ih = fdiv(pos, d_W);
-        const uint32_t iw = pos - ih * (uint32_t)W;
-        const float v = tensor_in_value(t, gbase + e, (int)c, C);
-        lds[s * chw_p + c * Hp * Wp + (ih + halo_h) * Wp + iw + halo_w] = v;
-        if (red != nullptr) atomicAdd(&red[c], v);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = 0; base < total; base += IG_THREADS * 4) {  // uniform trip count (shuffles inside)
+        const uint32_t e0 = base + threadIdx.x;
+        float v[4];
+        int cc[4], key[4], dst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t e = e0 + j * IG_THREADS;
+            v[j] = 0.f;
+            cc[j] = -1;
+            key[j] = -1;
+            dst[j] = -1;
+            if (e < total) {
+                const uint32_t s = fdiv(e, d_CHW);
+                const uint32_t r = e - s * (uint32_t)(C * HW);
+                const uint32_t c = fdiv(r, d_HW);
+                const uint32_t pos = r - c * (uint32_t)HW;
+                const uint32_t ih = fdiv(pos, d_W);
+                const uint32_t iw = pos - ih * (uint32_t)W;
+                v[j] = tensor_in_value(t, gbase + e, (int)c, C);
+                cc[j] = (int)c;
+                key[j] = (int)(s * C + c);  // run id: channel ids repeat from sample to sample
+                dst[j] = s * chw_p + c * Hp * Wp + (ih + halo_h) * Wp + iw + halo_w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (dst[j] >= 0) lds[dst[j]] = v[j];
+            if (red != nullptr) {  // uniform branch
+                float sum = v[j];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o = __shfl_down(sum, off, 64);
+                    const int ok = __shfl_down(key[j], off, 64);
+                    if (lane + off < 64 && ok == key[j]) sum += o;
+                }
+                const int pk = __shfl_up(key[j], 1, 64);
+                if (cc[j] >= 0 && (lane == 0 || pk != key[j])) atomicAdd(&red[cc[j]], sum);
+            }
+        }
     }
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) void igemm_gather_k(IgArgs a) {
+__global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
     float* lin = smem;
@@ -146,90 +165,74 @@ __global__ __launch_bounds__(256) void igemm_gather_k(IgArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int s0 = blockIdx.x * a.SB;
-    const int sb = min(a.SB, a.B - s0);
     const int HpWp = g.Hp * g.Wp, CinHpWp = g.Cin * HpWp;
-    const int ncls = g.so_h * g.so_w;
     const int OHW = g.OH * g.OW;
+    const int n_ntile = g.Np >> 4;
 
-    // 1. clear the input image (halo must read as zero)
-    for (int i = tid; i < a.lds_in; i += 256) lin[i] = 0.f;
-    for (int i = tid; i < 2 * g.Np; i += 256) red[i] = 0.f;
-    // 2. per class: tap offset table and the [k][n] weight image
-    {
-        int toff = 0, woff = 0;
-        for (int cls = 0; cls < ncls; ++cls) {
-            const IgClass c = ig_class(g, cls);
-            for (int k = tid; k < c.KcPad; k += 256) {
-                int off = 0;  // k >= Kc: weight row is zero, any finite in-range operand will do
-                if (k < c.Kc) {
-                    const int ci = k / c.ntaps, ti = k - ci * c.ntaps;
-                    const int i_h = ti / c.nkw, i_w = ti - i_h * c.nkw;
-                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
-                    int ro, co;
-                    if (g.transposed) {
-                        ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
-                        co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
-                    } else {
-                        ro = kh;
-                        co = kw;
-                    }
-                    off = ci * HpWp + ro * g.Wp + co;
+    // ---- once per workgroup: clear the input image (the halo must read as zero and is never
+    // written again), build the tap-offset tables and the [k][n] weight images of every class
+    for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
+    for (int cls = 0; cls < a.ncls; ++cls) {
+        const IgClass& c = a.cls[cls];
+        const int nw = c.KcPad * g.Np;
+        for (int i = tid; i < nw; i += IG_THREADS) {
+            const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
+            const int n = i - k * g.Np;
+            float v = 0.f;
+            int off = 0;  // k >= Kc: the weight row is zero, any finite in-range operand will do
+            if (k < c.Kc) {
+                const int ci = fdiv((uint32_t)k, c.d_ntaps), ti = k - ci * c.ntaps;
+                const int i_h = fdiv((uint32_t)ti, c.d_nkw), i_w = ti - i_h * c.nkw;
+                const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
+                int ro = kh, co = kw;
+                if (g.transposed) {
+                    ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
+                    co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
                 }
-                ktab[toff + k] = off;
+                off = ci * HpWp + ro * g.Wp + co;
+                if (n < g.N) v = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
             }
-            const int nw = c.KcPad * g.Np;
-            for (int i = tid; i < nw; i += 256) {
-                const int k = i / g.Np, n = i - k * g.Np;
-                float v = 0.f;
-                if (k < c.Kc && n < g.N) {
-                    const int ci = k / c.ntaps, ti = k - ci * c.ntaps;
-                    const int i_h = ti / c.nkw, i_w = ti - i_h * c.nkw;
-                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
-                    v = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
-                }
-                lw[woff + i] = v;
-            }
-            toff += c.KcPad;
-            woff += nw;
+            lw[c.woff + i] = v;
+            if (n == 0) ktab[c.toff + k] = off;
         }
     }
-    __syncthreads();
-    // 3. stage the chunk's input
-    ig_stage(a.in, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
-             g.d_CHW, g.d_HW, g.d_W, nullptr);
-    __syncthreads();
 
-    // 4. output tiles: 16 pixels of one class x 16*NT channels
-    {
-        int toff = 0, woff = 0, tile_base = 0;
-        const int n_ntile = g.Np / 16;
-        for (int cls = 0; cls < ncls; ++cls) {
-            const IgClass c = ig_class(g, cls);
+    for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        const int s0 = chunk * a.SB;
+        const int sb = min(a.SB, a.B - s0);
+        for (int i = tid; i < 2 * g.Np; i += IG_THREADS) red[i] = 0.f;
+        __syncthreads();  // previous chunk's copy-out is done with lout/red; tables are ready
+        ig_stage(a.in, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h,
+                 g.halo_w, g.d_CHW, g.d_HW, g.d_W, nullptr);
+        __syncthreads();
+
+        // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
+        int tile_base = 0;
+        for (int cls = 0; cls < a.ncls; ++cls) {
+            const IgClass& c = a.cls[cls];
             const int AHW = c.AH * c.AW;
             const int P = sb * AHW;
             const int ntile = (P + 15) >> 4;
-            // round-robin over waves, continuing across classes for balance
-            for (int t = (wid + 4 - (tile_base & 3)) & 3; t < ntile; t += 4) {
+            for (int t = (wid + IG_WAVES - (tile_base & (IG_WAVES - 1))) & (IG_WAVES - 1); t < ntile; t += IG_WAVES) {
                 const int q = t * 16 + li;
                 const bool valid = q < P;
                 const int qq = valid ? q : 0;
-                const int s = qq / AHW, rem = qq - s * AHW;
-                const int ah = rem / c.AW, aw = rem - ah * c.AW;
+                const int s = fdiv((uint32_t)qq, c.d_AHW), rem = qq - s * AHW;
+                const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
                 const int pixbase = s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
                 const int outoff = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
+                const int* kt = ktab + c.toff + lk;
                 for (int nc = 0; nc < n_ntile; nc += NT) {
                     f32x4 acc[NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const float* lwc = lw + woff + nc * 16 + li;
+                    const float* lwc = lw + c.woff + lk * g.Np + nc * 16 + li;
                     for (int k4 = 0; k4 < c.KcPad; k4 += 4) {
-                        const int k = k4 + lk;
-                        const float av = lin[pixbase + ktab[toff + k]];
+                        const float av = lin[pixbase + kt[k4]];
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             if (nc + j < n_ntile)
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lwc[k * g.Np + j * 16], acc[j], 0, 0, 0);
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lwc[k4 * g.Np + j * 16], acc[j], 0, 0, 0);
                     }
                     // D: col (channel) = li, row (pixel) = lk*4 + r
 #pragma unroll
@@ -247,69 +250,68 @@ __global__ __launch_bounds__(256) void igemm_gather_k(IgArgs a) {
                 }
             }
             tile_base += ntile;
-            toff += c.KcPad;
-            woff += c.KcPad * g.Np;
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // 5. write the chunk out (contiguous in global memory) + per-channel sums
-    const int64_t obase = (int64_t)s0 * g.N * OHW;
-    const int total = sb * g.N * OHW;
-    if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
-        for (int e = tid; e < total; e += 256) a.out[obase + e] = lout[e];
-        return;
-    }
-    // row-wise: one wave per (sample, channel) row so that each row's sums reduce by shuffles
-    const int rows = sb * g.N;
-    for (int row = wid; row < rows; row += 4) {
-        const int n = row % g.N;
-        float s1 = 0.f, s2 = 0.f;
-        float pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
-        if (a.ep_mode == EP_BNGRAD) {
-            mean = a.ep_coef[n];
-            rstd = a.ep_coef[g.N + n];
-            sc = a.ep_coef[2 * g.N + n];
-            sh = a.ep_coef[3 * g.N + n];
-        } else {
-            pv = lout[n * OHW];  // block-local pivot: this channel's first value in the chunk
+        // ---- write the chunk out (contiguous in global memory) + per-channel sums
+        const int64_t obase = (int64_t)s0 * g.N * OHW;
+        const int total = sb * g.N * OHW;
+        if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
+            for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = lout[e];
+            continue;
         }
-        for (int i = lane; i < OHW; i += 64) {
-            float v = lout[row * OHW + i];
+        // row-wise: one wave per (sample, channel) row so that each row's sums reduce by shuffles
+        const int rows = sb * g.N;
+        for (int row = wid; row < rows; row += IG_WAVES) {
+            const int n = row - (int)fdiv((uint32_t)row, a.d_N) * g.N;
+            float s1 = 0.f, s2 = 0.f;
+            float pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
             if (a.ep_mode == EP_BNGRAD) {
-                const float y = a.ep_y[obase + (int64_t)row * OHW + i];
-                if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
-                s1 += v;
-                s2 = fmaf(v, (y - mean) * rstd, s2);
+                mean = a.ep_coef[n];
+                rstd = a.ep_coef[g.N + n];
+                sc = a.ep_coef[2 * g.N + n];
+                sh = a.ep_coef[3 * g.N + n];
             } else {
-                const float d = v - pv;
-                s1 += d;
-                s2 = fmaf(d, d, s2);
+                pv = lout[n * OHW];  // chunk-local pivot: this channel's first value in the chunk
             }
-            a.out[obase + (int64_t)row * OHW + i] = v;
+            for (int i = lane; i < OHW; i += 64) {
+                float v = lout[row * OHW + i];
+                if (a.ep_mode == EP_BNGRAD) {
+                    const float y = a.ep_y[obase + (int64_t)row * OHW + i];
+                    if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
+                    s1 += v;
+                    s2 = fmaf(v, (y - mean) * rstd, s2);
+                } else {
+                    const float d = v - pv;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+                a.out[obase + (int64_t)row * OHW + i] = v;
+            }
+            if (a.slab != nullptr) {
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    atomicAdd(&red[2 * n], s1);
+                    atomicAdd(&red[2 * n + 1], s2);
+                }
+            }
         }
         if (a.slab != nullptr) {
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
-            if (lane == 0) {
-                atomicAdd(&red[2 * n], s1);
-                atomicAdd(&red[2 * n + 1], s2);
+            __syncthreads();
+            for (int n = tid; n < g.N; n += IG_THREADS) {
+                float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
+                if (a.ep_mode == EP_BNGRAD) {
+                    sl[0] = red[2 * n];
+                    sl[1] = red[2 * n + 1];
+                } else {
+                    sl[0] = lout[n * OHW];
+                    sl[1] = red[2 * n];
+                    sl[2] = red[2 * n + 1];
+                    sl[3] = (float)(sb * OHW);
+                }
             }
-        }
-    }
-    if (a.slab != nullptr) {
-        __syncthreads();
-        for (int n = tid; n < g.N; n += 256) {
-            float* sl = a.slab + ((int64_t)blockIdx.x * g.N + n) * 4;
-            if (a.ep_mode == EP_BNGRAD) {
-                sl[0] = red[2 * n];
-                sl[1] = red[2 * n + 1];
-            } else {
-                sl[0] = lout[n * OHW];
-                sl[1] = red[2 * n];
-                sl[2] = red[2 * n + 1];
-                sl[3] = (float)(sb * OHW);
-            }
+            __syncthreads();  // red is re-zeroed at the top of the next chunk
         }
     }
 }
@@ -318,113 +320,117 @@ __global__ __launch_bounds__(256) void igemm_gather_k(IgArgs a) {
 // dw[m][c][kh][kw] += sum_{b,oh,ow} S[b,m,oh,ow] * G[b,c,oh*sh-ph+kh,ow*sw-pw+kw]
 //   Conv : S = d(pre-activation) [Cout], G = layer input [Cin];  ConvT: S = layer input, G = d(pre-act).
 // MFMA: A[m][k=pixel] from the S tile, B[k=pixel][n=(c,tap)] gathered from the padded G tile.
-// The 4 waves split the pixel range; each holds ALL (m,n) tiles (<= WG_MAXT), reduced through
-// LDS at the end, then one atomicAdd per element and block.
+// Each workgroup loops over its chunks keeping ALL (m,n) accumulator tiles (<= WG_MAXT) in
+// registers; its waves split the pixels.  One cross-wave LDS reduction and one atomicAdd per
+// element happen per WORKGROUP, not per chunk.  The bias gradient is the per-channel sum of the
+// d(pre-activation) tensor, taken while it is staged.
 #define WG_MAXT 20
 
 struct WgArgs {
     TensorIn S, G;
     float* dw;
-    float* dbias;     // bias gradient (sum of the d(pre-act) tensor per channel) or nullptr
+    float* dbias;     // bias gradient or nullptr
     int bias_from_S;  // 1: dbias from S (Conv), 0: from G (ConvT)
-    int B, SB;
+    int B, SB, nchunks;
     int Sc, SH, SW;   // S: channels, small grid
     int Gc, GH, GW;   // G: channels, big grid
     int KH, KW, sh, sw, ph, pw;
     int Hp, Wp;       // padded G image (halo = ph, pw low side)
     int Mp, NKp;      // Sc and Gc*KH*KW rounded up to 16
-    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW;
+    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW;
     int lds_S, lds_G, lds_tab;
 };
 
-__global__ __launch_bounds__(256) void igemm_wgrad_k(WgArgs a) {
+__global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lS = smem;                 // [sb][Sc][SHW]
     float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]
-    int* ptab = reinterpret_cast<int*>(lG + a.lds_G);  // per pixel: packed (S offset, G base)
+    int* ptab = reinterpret_cast<int*>(lG + a.lds_G);  // per pixel: (S offset, G base)
     float* red = reinterpret_cast<float*>(ptab + a.lds_tab);  // [max(Sc,Gc)]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int s0 = blockIdx.x * a.SB;
-    const int sb = min(a.SB, a.B - s0);
     const int SHW = a.SH * a.SW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW;
     const int NK = a.Gc * KK;
-    const int P = sb * SHW;
-    const int Ppad = (P + 3) & ~3;
+    const int Pfull = a.SB * SHW;
 
-    for (int i = tid; i < a.lds_G; i += 256) lG[i] = 0.f;
-    for (int i = tid; i < a.lds_S; i += 256) lS[i] = 0.f;
+    for (int i = tid; i < a.lds_G; i += IG_THREADS) lG[i] = 0.f;  // halo stays zero for every chunk
     const int nred = a.bias_from_S ? a.Sc : a.Gc;
-    for (int i = tid; i < nred; i += 256) red[i] = 0.f;
-    // pixel table: q -> S offset (s*Sc*SHW + pix) and G base (s*Gc*HpWp + oh*sh*Wp + ow*sw)
-    for (int q = tid; q < Ppad; q += 256) {
-        int so = 0, gb = 0;  // padded pixels: operands are forced to zero at the read
-        if (q < P) {
-            const int s = q / SHW, pix = q - s * SHW;
-            const int oh = pix / a.SW, ow = pix - oh * a.SW;
+    for (int i = tid; i < nred; i += IG_THREADS) red[i] = 0.f;
+    // pixel table (same for every chunk): q -> S offset (s*Sc*SHW + pix), G base (s*Gc*HpWp + oh*sh*Wp + ow*sw)
+    for (int q = tid; q < ((Pfull + 3) & ~3); q += IG_THREADS) {
+        int so = 0, gb = 0;
+        if (q < Pfull) {
+            const int s = fdiv((uint32_t)q, a.dS_HW), pix = q - s * SHW;
+            const int oh = fdiv((uint32_t)pix, a.dS_W), ow = pix - oh * a.SW;
             so = s * a.Sc * SHW + pix;
             gb = s * a.Gc * HpWp + oh * a.sh * a.Wp + ow * a.sw;
         }
         ptab[2 * q] = so;
         ptab[2 * q + 1] = gb;
     }
-    __syncthreads();
-    ig_stage(a.S, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W,
-             (a.dbias != nullptr && a.bias_from_S) ? red : nullptr);
-    ig_stage(a.G, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
-             a.dG_CHW, a.dG_HW, a.dG_W, (a.dbias != nullptr && !a.bias_from_S) ? red : nullptr);
-    __syncthreads();
-    if (a.dbias != nullptr)
-        for (int i = tid; i < nred; i += 256) atomicAdd(&a.dbias[i], red[i]);
 
-    const int MT = a.Mp / 16, NTt = a.NKp / 16, T = MT * NTt;
-    // per-lane constants: B column n = nt*16 + li -> tap offset in the G image (or the zero pad)
+    const int MT = a.Mp >> 4, NTt = a.NKp >> 4, T = MT * NTt;
+    // per-lane constants: B column n = nt*16 + li -> tap offset in the G image
     int koffN[WG_MAXT];
     f32x4 acc[WG_MAXT];
-#pragma unroll
-    for (int t = 0; t < WG_MAXT; ++t) {
-        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        koffN[t] = 0;
-    }
     bool nvalid[WG_MAXT];
 #pragma unroll
     for (int nt = 0; nt < WG_MAXT; ++nt) {
+        acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        koffN[nt] = 0;
         nvalid[nt] = false;
         if (nt < NTt) {
             const int n = nt * 16 + li;
             if (n < NK) {
-                const int c = n / KK, tap = n - c * KK;
-                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                const int c = fdiv((uint32_t)n, a.d_KK), tap = n - c * KK;
+                const int kh = fdiv((uint32_t)tap, a.d_KW), kw = tap - kh * a.KW;
                 koffN[nt] = c * HpWp + kh * a.Wp + kw;
                 nvalid[nt] = true;
             }
         }
     }
-    // pixels: wave w takes steps w, w+4, ... (4 pixels per MFMA step)
-    for (int q4 = wid * 4; q4 < Ppad; q4 += 16) {
-        const int q = q4 + lk;
-        const int so = ptab[2 * q], gb = ptab[2 * q + 1];
-        float av[2];
+
+    for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        const int s0 = chunk * a.SB;
+        const int sb = min(a.SB, a.B - s0);
+        const int P = sb * SHW;
+        const int Ppad = (P + 3) & ~3;
+        __syncthreads();  // tables ready / previous chunk's MFMAs are done with the tiles
+        ig_stage(a.S, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W,
+                 (a.dbias != nullptr && a.bias_from_S) ? red : nullptr);
+        ig_stage(a.G, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
+                 a.dG_CHW, a.dG_HW, a.dG_W, (a.dbias != nullptr && !a.bias_from_S) ? red : nullptr);
+        __syncthreads();
+        // pixels: wave w takes steps w, w+IG_WAVES, ... (4 pixels per MFMA step)
+        for (int q4 = wid * 4; q4 < Ppad; q4 += 4 * IG_WAVES) {
+            const int q = q4 + lk;
+            const bool qv = q < P;
+            const int so = ptab[2 * q], gb = ptab[2 * q + 1];
+            float av[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) av[mt] = (mt < MT && mt * 16 + li < a.Sc && q < P) ? lS[so + (mt * 16 + li) * SHW] : 0.f;
+            for (int mt = 0; mt < 2; ++mt)
+                av[mt] = (mt < MT && mt * 16 + li < a.Sc && qv) ? lS[so + (mt * 16 + li) * SHW] : 0.f;
 #pragma unroll
-        for (int nt = 0; nt < WG_MAXT; ++nt) {
-            if (nt < NTt) {
-                const float bv = (nvalid[nt] && q < P) ? lG[gb + koffN[nt]] : 0.f;
-                if (MT == 1) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[nt], 0, 0, 0);
-                else if (2 * nt + 1 < WG_MAXT) {
-                    acc[2 * nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[2 * nt], 0, 0, 0);
-                    acc[2 * nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv, acc[2 * nt + 1], 0, 0, 0);
+            for (int nt = 0; nt < WG_MAXT; ++nt) {
+                if (nt < NTt) {
+                    const float bv = (nvalid[nt] && qv) ? lG[gb + koffN[nt]] : 0.f;
+                    if (MT == 1) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[nt], 0, 0, 0);
+                    else if (2 * nt + 1 < WG_MAXT) {
+                        acc[2 * nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[2 * nt], 0, 0, 0);
+                        acc[2 * nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv, acc[2 * nt + 1], 0, 0, 0);
+                    }
                 }
             }
         }
     }
     __syncthreads();
+    if (a.dbias != nullptr)
+        for (int i = tid; i < nred; i += IG_THREADS) atomicAdd(&a.dbias[i], red[i]);
     // cross-wave reduction through LDS: waves add their tiles in turn into rbuf[T][4][64]
     // (overlays the S/G tiles, which are dead now; the host sizes lds_S + lds_G >= T*256)
     float* rbuf = smem;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < IG_WAVES; ++w) {
         if (wid == w) {
 #pragma unroll
             for (int t = 0; t < WG_MAXT; ++t)
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_k(WgArgs a) {
         }
         __syncthreads();
     }
-    for (int i = tid; i < T * 256; i += 256) {
+    for (int i = tid; i < T * 256; i += IG_THREADS) {
         const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
         int mt, nt;
         if (MT == 1) { mt = 0; nt = t; }

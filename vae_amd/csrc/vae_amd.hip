@@ -238,7 +238,8 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 
 
 // ---- fused implicit-GEMM conv path (igemm.h) ------------------------------------------------
-#define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two workgroups per CU
+#define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
+#define IG_MAX_GRID 512             // persistent workgroups: 2 per CU, each loops over its chunks
 
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
@@ -296,31 +297,51 @@ static IgGeom make_geom(int transposed, int Cin, int H, int W, int N, int OH, in
 struct IgPlan {
     int SB, lds_in, lds_w, lds_out, lds_tab, total;
 };
-// LDS need of the gather kernel for SB samples per block; picks SB for batch B (0 if it cannot fit)
+// Host mirror of the per-class tap enumeration (igemm.h IgClass); returns the class count.
+static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
+    const int ncls = g.so_h * g.so_w;
+    int toff = 0, woff = 0;
+    for (int i = 0; i < ncls; ++i) {
+        IgClass& c = cls[i];
+        c.rh = i / g.so_w; c.rw = i % g.so_w;
+        c.AH = (g.OH - c.rh + g.so_h - 1) / g.so_h;
+        c.AW = (g.OW - c.rw + g.so_w - 1) / g.so_w;
+        if (c.AH < 0) c.AH = 0;
+        if (c.AW < 0) c.AW = 0;
+        if (g.transposed) {
+            c.kh0 = (c.rh + g.ph) % g.so_h; c.kw0 = (c.rw + g.pw) % g.so_w;
+            c.nkh = c.kh0 < g.KH ? (g.KH - c.kh0 + g.so_h - 1) / g.so_h : 0;
+            c.nkw = c.kw0 < g.KW ? (g.KW - c.kw0 + g.so_w - 1) / g.so_w : 0;
+        } else {
+            c.kh0 = c.kw0 = 0; c.nkh = g.KH; c.nkw = g.KW;
+        }
+        c.ntaps = c.nkh * c.nkw;
+        c.Kc = g.Cin * c.ntaps;
+        c.KcPad = (c.Kc + 3) & ~3;
+        c.toff = toff; c.woff = woff;
+        c.d_ntaps = mk_fdiv(c.ntaps > 0 ? c.ntaps : 1);
+        c.d_nkw = mk_fdiv(c.nkw > 0 ? c.nkw : 1);
+        c.d_AHW = mk_fdiv(c.AH * c.AW > 0 ? c.AH * c.AW : 1);
+        c.d_AW = mk_fdiv(c.AW > 0 ? c.AW : 1);
+        toff += c.KcPad; woff += c.KcPad * g.Np;
+    }
+    *wsum = woff; *tsum = toff;
+    return ncls;
+}
+// LDS need of the gather kernel for SB samples per chunk; picks SB for batch B (0 if it cannot fit)
 static IgPlan plan_gather(const IgGeom& g, int B) {
     IgPlan p;
+    IgClass cls[4];
     int wsum = 0, tsum = 0;
-    const int ncls = g.so_h * g.so_w;
-    for (int cls = 0; cls < ncls; ++cls) {
-        int nkh, nkw;
-        if (g.transposed) {
-            const int rh = cls / g.so_w, rw = cls % g.so_w;
-            const int kh0 = (rh + g.ph) % g.so_h, kw0 = (rw + g.pw) % g.so_w;
-            nkh = kh0 < g.KH ? (g.KH - kh0 + g.so_h - 1) / g.so_h : 0;
-            nkw = kw0 < g.KW ? (g.KW - kw0 + g.so_w - 1) / g.so_w : 0;
-        } else { nkh = g.KH; nkw = g.KW; }
-        const int KcPad = (g.Cin * nkh * nkw + 3) & ~3;
-        wsum += KcPad * g.Np;
-        tsum += KcPad;
-    }
+    if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
+    fill_classes(g, cls, &wsum, &tsum);
     const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW;
     const int fixed = wsum + tsum + 2 * g.Np + 8;
     int fit = (IG_LDS_BUDGET_FLOATS - fixed) / (per_in + per_out);
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1) {
-        sb = (B + 1023) / 1024;                       // >= ~1024 blocks when the batch allows
-        while (sb < fit && sb * per_in < wsum) ++sb;  // amortise the per-block weight image
+        sb = (B + 2047) / 2048;  // aim for >= 4 chunks per resident workgroup when the batch allows
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
         if (sb > B) sb = B;
@@ -328,7 +349,9 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     p.SB = sb;
     p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * per_out; p.lds_tab = tsum;
     p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + 2 * g.Np;
-    if ((uint64_t)(p.lds_in > p.lds_out ? p.lds_in : p.lds_out) * (uint64_t)(g.Cin * g.H * g.W + 1) >= ((uint64_t)1 << 32)) p.SB = 0;
+    // FastDiv exactness bound: n * d < 2^32 for every (n, d) pair the kernels divide
+    const uint64_t nmax = (uint64_t)(p.lds_in > p.lds_out ? p.lds_in : p.lds_out) + wsum;
+    if (nmax * (uint64_t)(g.Cin * g.H * g.W + g.N * g.OH * g.OW + 1) >= ((uint64_t)1 << 32)) p.SB = 0;
     return p;
 }
 
@@ -349,7 +372,7 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1 && p.Mp <= 32 && T <= WG_MAXT) {
-        sb = (B + 1023) / 1024;
+        sb = (B + 2047) / 2048;
         while (sb < fit && sb * (per_S + per_G) < T * 256) ++sb;  // room for the cross-wave reduction image
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
@@ -387,14 +410,19 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     if (p.SB < 1) VAE_FAIL(VAE_EINVAL, "%s: layer does not fit the fused conv kernel's LDS budget", what);
     a.B = c.B; a.SB = p.SB;
     a.lds_in = p.lds_in; a.lds_w = p.lds_w; a.lds_out = p.lds_out; a.lds_tab = p.lds_tab;
-    const int grid = (c.B + p.SB - 1) / p.SB;
+    int wsum, tsum;
+    a.ncls = fill_classes(a.g, a.cls, &wsum, &tsum);
+    a.nchunks = (c.B + p.SB - 1) / p.SB;
+    a.d_N = mk_fdiv(a.g.N);
+    a.d_ntile = mk_fdiv(a.g.Np / 16);
+    const int grid = a.nchunks < IG_MAX_GRID ? a.nchunks : IG_MAX_GRID;
     const size_t bytes = (size_t)p.total * sizeof(float);
     if (a.g.Np > 16)
-        hipLaunchKernelGGL(igemm_gather_k<2>, dim3(grid), dim3(256), bytes, c.s, a);
+        hipLaunchKernelGGL(igemm_gather_k<2>, dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
     else
-        hipLaunchKernelGGL(igemm_gather_k<1>, dim3(grid), dim3(256), bytes, c.s, a);
+        hipLaunchKernelGGL(igemm_gather_k<1>, dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
     VAE_LAUNCH_CHECK(what);
-    if (a.slab != nullptr) c.last_blocks = grid;
+    if (a.slab != nullptr) c.last_blocks = a.nchunks;
     return VAE_OK;
 }
 
@@ -491,9 +519,11 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     wa.Hp = wp.Hp; wa.Wp = wp.Wp; wa.Mp = wp.Mp; wa.NKp = wp.NKp;
     wa.dS_HW = mk_fdiv(wa.SH * wa.SW); wa.dS_W = mk_fdiv(wa.SW); wa.dS_CHW = mk_fdiv(wa.Sc * wa.SH * wa.SW);
     wa.dG_HW = mk_fdiv(wa.GH * wa.GW); wa.dG_W = mk_fdiv(wa.GW); wa.dG_CHW = mk_fdiv(wa.Gc * wa.GH * wa.GW);
+    wa.d_KK = mk_fdiv(g.KH * g.KW); wa.d_KW = mk_fdiv(g.KW);
     wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
-    hipLaunchKernelGGL(igemm_wgrad_k, dim3((c.B + wp.SB - 1) / wp.SB), dim3(256), (size_t)wp.total * sizeof(float), c.s,
-                       wa);
+    wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
+    hipLaunchKernelGGL(igemm_wgrad_k, dim3(wa.nchunks < IG_MAX_GRID ? wa.nchunks : IG_MAX_GRID), dim3(IG_THREADS),
+                       (size_t)wp.total * sizeof(float), c.s, wa);
     VAE_LAUNCH_CHECK("igemm_wgrad_k");
 
     // 2) input gradient
