@@ -34,6 +34,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;  // valid in lane 0
 }
 
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, VAE_WAVE);
+    return v;  // valid in every lane
+}
+
 // Sum over a 256-thread block; result valid in thread 0.  `sm` >= 4 floats of LDS.
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
     v = wave_sum(v);

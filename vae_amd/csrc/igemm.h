@@ -34,14 +34,15 @@ struct TensorIn {
     float slope;
 };
 
-__device__ __forceinline__ float tensor_in_value(const TensorIn& t, int64_t e, int c, int C) {
+// `coef` is the LDS copy of t.coef (8*C floats) made once per workgroup.
+__device__ __forceinline__ float tensor_in_value(const TensorIn& t, const float* coef, int64_t e, int c, int C) {
     float v = t.src[e];
     if (t.mode == TR_BN) {
-        v = fmaf(v - t.coef[c], t.coef[2 * C + c], t.coef[3 * C + c]);  // (y - mean) * scale + beta
+        v = fmaf(v - coef[c], coef[2 * C + c], coef[3 * C + c]);  // (y - mean) * scale + beta
         if (t.relu) v = v > 0.f ? v : 0.f;
     } else if (t.mode == TR_GRAD_BN) {
         const float y = t.src2[e];
-        v = fmaf(t.coef[4 * C + c], v, fmaf(t.coef[5 * C + c], y - t.coef[c], t.coef[6 * C + c]));
+        v = fmaf(coef[4 * C + c], v, fmaf(coef[5 * C + c], y - coef[c], coef[6 * C + c]));
         v *= act_grad_from_out(y, t.act, t.slope);
     } else if (t.mode == TR_GRAD_ACT) {
         v *= act_grad_from_out(t.src2[e], t.act, t.slope);
@@ -94,33 +95,29 @@ struct IgArgs {
     // LDS carve (floats)
     int lds_in, lds_w, lds_out, lds_tab;
     int ncls, nchunks;
+    int dbg;  // ablation mask (VAE_DBG_SKIPG env, diagnostics only)
     FastDiv d_N, d_ntile;  // by N and by Np/16
     IgClass cls[4];
 };
 
 #define IG_THREADS 512
 #define IG_WAVES (IG_THREADS / 64)
+#define IG_UNROLL 8
 
 // Stage [sb][C][H][W] (global, contiguous) into the padded LDS image, applying the transform.
-// Optionally accumulates per-channel sums of the staged values into red[c]: lanes hold consecutive
-// elements, so equal channels form contiguous runs; a segmented shuffle reduction leaves each run's
-// sum in its first lane, which issues the only LDS atomic of the run.
-__device__ __forceinline__ void ig_stage(const TensorIn& t, float* lds, int64_t gbase, int sb, int C, int HW, int W,
-                                         int Hp, int Wp, int halo_h, int halo_w, FastDiv d_CHW, FastDiv d_HW,
-                                         FastDiv d_W, float* red) {
+// IG_UNROLL independent elements per lane and iteration: all their global loads are in flight
+// together before the first LDS store (the kernels are latency-bound at these chunk sizes).
+__device__ __forceinline__ void ig_stage(const TensorIn& t, const float* coef, float* lds, int64_t gbase, int sb,
+                                         int C, int HW, int W, int Hp, int Wp, int halo_h, int halo_w,
+                                         FastDiv d_CHW, FastDiv d_HW, FastDiv d_W) {
     const uint32_t total = (uint32_t)sb * C * HW;
     const int chw_p = C * Hp * Wp;
-    const int lane = threadIdx.x & 63;
-    for (uint32_t base = 0; base < total; base += IG_THREADS * 4) {  // uniform trip count (shuffles inside)
-        const uint32_t e0 = base + threadIdx.x;
-        float v[4];
-        int cc[4], key[4], dst[4];
+    for (uint32_t base = threadIdx.x; base < total; base += IG_THREADS * IG_UNROLL) {
+        float v[IG_UNROLL];
+        int dst[IG_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t e = e0 + j * IG_THREADS;
-            v[j] = 0.f;
-            cc[j] = -1;
-            key[j] = -1;
+        for (int j = 0; j < IG_UNROLL; ++j) {
+            const uint32_t e = base + j * IG_THREADS;
             dst[j] = -1;
             if (e < total) {
                 const uint32_t s = fdiv(e, d_CHW);
@@ -129,28 +126,19 @@ __device__ __forceinline__ void ig_stage(const TensorIn& t, float* lds, int64_t 
                 const uint32_t pos = r - c * (uint32_t)HW;
                 const uint32_t ih = fdiv(pos, d_W);
                 const uint32_t iw = pos - ih * (uint32_t)W;
-                v[j] = tensor_in_value(t, gbase + e, (int)c, C);
-                cc[j] = (int)c;
-                key[j] = (int)(s * C + c);  // run id: channel ids repeat from sample to sample
+                v[j] = tensor_in_value(t, coef, gbase + e, (int)c, C);
                 dst[j] = s * chw_p + c * Hp * Wp + (ih + halo_h) * Wp + iw + halo_w;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < IG_UNROLL; ++j)
             if (dst[j] >= 0) lds[dst[j]] = v[j];
-            if (red != nullptr) {  // uniform branch
-                float sum = v[j];
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const float o = __shfl_down(sum, off, 64);
-                    const int ok = __shfl_down(key[j], off, 64);
-                    if (lane + off < 64 && ok == key[j]) sum += o;
-                }
-                const int pk = __shfl_up(key[j], 1, 64);
-                if (cc[j] >= 0 && (lane == 0 || pk != key[j])) atomicAdd(&red[cc[j]], sum);
-            }
-        }
     }
+}
+
+__device__ __forceinline__ void ig_load_coef(const float* g, float* l, int n) {
+    if (g != nullptr)
+        for (int i = threadIdx.x; i < n; i += IG_THREADS) l[i] = g[i];
 }
 
 template <int NT>
@@ -161,17 +149,24 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     float* lw = lin + a.lds_in;
     float* lout = lw + a.lds_w;
     int* ktab = reinterpret_cast<int*>(lout + a.lds_out);
-    float* red = reinterpret_cast<float*>(ktab + a.lds_tab);  // [Np][2]
+    float* cin = reinterpret_cast<float*>(ktab + a.lds_tab);  // [8*Cin] input transform coefficients
+    float* cep = cin + 8 * g.Cin;                             // [8*N]   epilogue (producer BN) coefficients
+    float* lbias = cep + 8 * g.N;                             // [Np]    bias (zero padded)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int HpWp = g.Hp * g.Wp, CinHpWp = g.Cin * HpWp;
     const int OHW = g.OH * g.OW;
     const int n_ntile = g.Np >> 4;
+    if (a.dbg & 32) return;
 
     // ---- once per workgroup: clear the input image (the halo must read as zero and is never
     // written again), build the tap-offset tables and the [k][n] weight images of every class
     for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
+    ig_load_coef(a.in.coef, cin, 8 * g.Cin);
+    ig_load_coef(a.ep_coef, cep, 8 * g.N);
+    for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
+    if (!(a.dbg & 8))
     for (int cls = 0; cls < a.ncls; ++cls) {
         const IgClass& c = a.cls[cls];
         const int nw = c.KcPad * g.Np;
@@ -200,14 +195,15 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
-        for (int i = tid; i < 2 * g.Np; i += IG_THREADS) red[i] = 0.f;
-        __syncthreads();  // previous chunk's copy-out is done with lout/red; tables are ready
-        ig_stage(a.in, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h,
-                 g.halo_w, g.d_CHW, g.d_HW, g.d_W, nullptr);
+        __syncthreads();  // previous chunk's copy-out is done with lout; tables/coefficients are ready
+        if (!(a.dbg & 1))
+        ig_stage(a.in, cin, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h,
+                 g.halo_w, g.d_CHW, g.d_HW, g.d_W);
         __syncthreads();
 
         // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
         int tile_base = 0;
+        if (!(a.dbg & 2))
         for (int cls = 0; cls < a.ncls; ++cls) {
             const IgClass& c = a.cls[cls];
             const int AHW = c.AH * c.AW;
@@ -219,20 +215,33 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
                 const int qq = valid ? q : 0;
                 const int s = fdiv((uint32_t)qq, c.d_AHW), rem = qq - s * AHW;
                 const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
-                const int pixbase = s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
+                const float* lp = lin + s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
                 const int outoff = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
                 const int* kt = ktab + c.toff + lk;
                 for (int nc = 0; nc < n_ntile; nc += NT) {
                     f32x4 acc[NT];
+                    float bias_r[NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < NT; ++j) {
+                        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        bias_r[j] = (nc + j < n_ntile) ? lbias[(nc + j) * 16 + li] : 0.f;
+                    }
                     const float* lwc = lw + c.woff + lk * g.Np + nc * 16 + li;
-                    for (int k4 = 0; k4 < c.KcPad; k4 += 4) {
-                        const float av = lin[pixbase + kt[k4]];
+                    // KcPad is a multiple of 16: four independent k-steps per iteration so that the
+                    // table read -> gather read -> MFMA chains of different steps overlap
+                    for (int k4 = 0; k4 < c.KcPad; k4 += 16) {
+                        const int o0 = kt[k4], o1 = kt[k4 + 4], o2 = kt[k4 + 8], o3 = kt[k4 + 12];
+                        const float a0 = lp[o0], a1 = lp[o1], a2 = lp[o2], a3 = lp[o3];
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            if (nc + j < n_ntile)
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lwc[k4 * g.Np + j * 16], acc[j], 0, 0, 0);
+                            if (nc + j < n_ntile) {
+                                const float* wj = lwc + k4 * g.Np + j * 16;
+                                const float b0 = wj[0], b1 = wj[4 * g.Np], b2 = wj[8 * g.Np], b3 = wj[12 * g.Np];
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[j], 0, 0, 0);
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[j], 0, 0, 0);
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc[j], 0, 0, 0);
+                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc[j], 0, 0, 0);
+                            }
                     }
                     // D: col (channel) = li, row (pixel) = lk*4 + r
 #pragma unroll
@@ -241,10 +250,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
                             const int n = (nc + j) * 16 + li;
-                            if (oo >= 0 && n < g.N) {
-                                float v = acc[j][r] + (a.bias != nullptr ? a.bias[n] : 0.f);
-                                lout[oo + n * OHW] = act_apply(v, a.act, a.slope);
-                            }
+                            if (oo >= 0 && n < g.N) lout[oo + n * OHW] = acc[j][r] + bias_r[j];
                         }
                     }
                 }
@@ -256,62 +262,58 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
         const int64_t obase = (int64_t)s0 * g.N * OHW;
         const int total = sb * g.N * OHW;
+        if (a.dbg & 4) continue;
         if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
-            for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = lout[e];
+            // (the activation runs here, once per real output element with every lane busy, not in the
+            // MFMA epilogue where 15 of 16 lanes may hold padding channels)
+            for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
             continue;
         }
-        // row-wise: one wave per (sample, channel) row so that each row's sums reduce by shuffles
-        const int rows = sb * g.N;
-        for (int row = wid; row < rows; row += IG_WAVES) {
-            const int n = row - (int)fdiv((uint32_t)row, a.d_N) * g.N;
-            float s1 = 0.f, s2 = 0.f;
-            float pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
+        // one wave per channel: it walks that channel's row in every sample of the chunk, so the two
+        // sums stay in registers and are reduced once; no atomics, fixed order => deterministic
+        for (int n = wid; n < g.N; n += IG_WAVES) {
+            float s1 = 0.f, s2 = 0.f, pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
             if (a.ep_mode == EP_BNGRAD) {
-                mean = a.ep_coef[n];
-                rstd = a.ep_coef[g.N + n];
-                sc = a.ep_coef[2 * g.N + n];
-                sh = a.ep_coef[3 * g.N + n];
+                mean = cep[n];
+                rstd = cep[g.N + n];
+                sc = cep[2 * g.N + n];
+                sh = cep[3 * g.N + n];
             } else {
-                pv = lout[n * OHW];  // chunk-local pivot: this channel's first value in the chunk
+                pv = act_apply(lout[n * OHW], a.act, a.slope);  // chunk-local pivot: the channel's first value
             }
-            for (int i = lane; i < OHW; i += 64) {
-                float v = lout[row * OHW + i];
-                if (a.ep_mode == EP_BNGRAD) {
-                    const float y = a.ep_y[obase + (int64_t)row * OHW + i];
-                    if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
-                    s1 += v;
-                    s2 = fmaf(v, (y - mean) * rstd, s2);
-                } else {
-                    const float d = v - pv;
-                    s1 += d;
-                    s2 = fmaf(d, d, s2);
+            for (int s = 0; s < sb; ++s) {
+                const int rbase = (s * g.N + n) * OHW;
+                for (int i = lane; i < OHW; i += 64) {
+                    float v = act_apply(lout[rbase + i], a.act, a.slope);
+                    if (a.ep_mode == EP_BNGRAD) {
+                        const float y = a.ep_y[obase + rbase + i];
+                        if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
+                        s1 += v;
+                        s2 = fmaf(v, (y - mean) * rstd, s2);
+                    } else {
+                        const float d = v - pv;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                    a.out[obase + rbase + i] = v;
                 }
-                a.out[obase + (int64_t)row * OHW + i] = v;
             }
             if (a.slab != nullptr) {
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
                 if (lane == 0) {
-                    atomicAdd(&red[2 * n], s1);
-                    atomicAdd(&red[2 * n + 1], s2);
+                    float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
+                    if (a.ep_mode == EP_BNGRAD) {
+                        sl[0] = s1;
+                        sl[1] = s2;
+                    } else {
+                        sl[0] = pv;
+                        sl[1] = s1;
+                        sl[2] = s2;
+                        sl[3] = (float)(sb * OHW);
+                    }
                 }
             }
-        }
-        if (a.slab != nullptr) {
-            __syncthreads();
-            for (int n = tid; n < g.N; n += IG_THREADS) {
-                float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
-                if (a.ep_mode == EP_BNGRAD) {
-                    sl[0] = red[2 * n];
-                    sl[1] = red[2 * n + 1];
-                } else {
-                    sl[0] = lout[n * OHW];
-                    sl[1] = red[2 * n];
-                    sl[2] = red[2 * n + 1];
-                    sl[3] = (float)(sb * OHW);
-                }
-            }
-            __syncthreads();  // red is re-zeroed at the top of the next chunk
         }
     }
 }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
 // Each workgroup loops over its chunks keeping ALL (m,n) accumulator tiles (<= WG_MAXT) in
 // registers; its waves split the pixels.  One cross-wave LDS reduction and one atomicAdd per
 // element happen per WORKGROUP, not per chunk.  The bias gradient is the per-channel sum of the
-// d(pre-activation) tensor, taken while it is staged.
+// d(pre-activation) tensor, taken from its LDS image (a zero halo adds nothing).
 #define WG_MAXT 20
 
 struct WgArgs {
@@ -339,6 +341,7 @@ struct WgArgs {
     int Mp, NKp;      // Sc and Gc*KH*KW rounded up to 16
     FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW;
     int lds_S, lds_G, lds_tab;
+    int dbg;  // ablation mask (VAE_DBG_SKIP env, diagnostics only)
 };
 
 __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
@@ -346,18 +349,22 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
     float* lS = smem;                 // [sb][Sc][SHW]
     float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]
     int* ptab = reinterpret_cast<int*>(lG + a.lds_G);  // per pixel: (S offset, G base)
-    float* red = reinterpret_cast<float*>(ptab + a.lds_tab);  // [max(Sc,Gc)]
+    float* cS = reinterpret_cast<float*>(ptab + a.lds_tab);  // [8*Sc] transform coefficients of S
+    float* cG = cS + 8 * a.Sc;                                // [8*Gc] ... of G
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int SHW = a.SH * a.SW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW;
     const int NK = a.Gc * KK;
     const int Pfull = a.SB * SHW;
+    if (a.dbg & 32) return;
 
+    if (!(a.dbg & 64))
     for (int i = tid; i < a.lds_G; i += IG_THREADS) lG[i] = 0.f;  // halo stays zero for every chunk
-    const int nred = a.bias_from_S ? a.Sc : a.Gc;
-    for (int i = tid; i < nred; i += IG_THREADS) red[i] = 0.f;
+    ig_load_coef(a.S.coef, cS, 8 * a.Sc);
+    ig_load_coef(a.G.coef, cG, 8 * a.Gc);
     // pixel table (same for every chunk): q -> S offset (s*Sc*SHW + pix), G base (s*Gc*HpWp + oh*sh*Wp + ow*sw)
+    if (!(a.dbg & 128))
     for (int q = tid; q < ((Pfull + 3) & ~3); q += IG_THREADS) {
         int so = 0, gb = 0;
         if (q < Pfull) {
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
             }
         }
     }
+    float bsum = 0.f;  // lane 0 of wave w: bias partial of the channels that wave owns
 
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int s0 = chunk * a.SB;
@@ -397,12 +405,28 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
         const int P = sb * SHW;
         const int Ppad = (P + 3) & ~3;
         __syncthreads();  // tables ready / previous chunk's MFMAs are done with the tiles
-        ig_stage(a.S, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W,
-                 (a.dbias != nullptr && a.bias_from_S) ? red : nullptr);
-        ig_stage(a.G, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
-                 a.dG_CHW, a.dG_HW, a.dG_W, (a.dbias != nullptr && !a.bias_from_S) ? red : nullptr);
+        if (!(a.dbg & 1))
+        ig_stage(a.S, cS, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW,
+                 a.dS_W);
+        if (!(a.dbg & 2))
+        ig_stage(a.G, cG, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
+                 a.dG_CHW, a.dG_HW, a.dG_W);
         __syncthreads();
+        // bias gradient: channel c is owned by wave (c % IG_WAVES); at most 4 channels per wave here
+        if (a.dbias != nullptr && !(a.dbg & 16)) {
+            const float* img = a.bias_from_S ? lS : lG;
+            const int C = a.bias_from_S ? a.Sc : a.Gc;
+            const int rowlen = a.bias_from_S ? SHW : HpWp;
+            for (int c = wid, slot = 0; c < C; c += IG_WAVES, ++slot) {
+                float t = 0.f;
+                for (int s = 0; s < sb; ++s)
+                    for (int i = lane; i < rowlen; i += 64) t += img[(s * C + c) * rowlen + i];
+                t = wave_sum_all(t);
+                if (lane == slot) bsum += t;  // lane `slot` of this wave accumulates channel wid + slot*IG_WAVES
+            }
+        }
         // pixels: wave w takes steps w, w+IG_WAVES, ... (4 pixels per MFMA step)
+        if (!(a.dbg & 4))
         for (int q4 = wid * 4; q4 < Ppad; q4 += 4 * IG_WAVES) {
             const int q = q4 + lk;
             const bool qv = q < P;
@@ -425,11 +449,18 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
         }
     }
     __syncthreads();
-    if (a.dbias != nullptr)
-        for (int i = tid; i < nred; i += IG_THREADS) atomicAdd(&a.dbias[i], red[i]);
+    if (a.dbias != nullptr) {  // gather the per-wave partials in LDS: ONE atomic wave-instruction per workgroup
+        const int C = a.bias_from_S ? a.Sc : a.Gc;
+        const int c = wid + lane * IG_WAVES;
+        if (lane < 8 && c < C) smem[c] = bsum;
+        __syncthreads();
+        if (tid < C) atomicAdd(&a.dbias[tid], smem[tid]);
+        __syncthreads();
+    }
     // cross-wave reduction through LDS: waves add their tiles in turn into rbuf[T][4][64]
     // (overlays the S/G tiles, which are dead now; the host sizes lds_S + lds_G >= T*256)
     float* rbuf = smem;
+    if (a.dbg & 8) return;
     for (int w = 0; w < IG_WAVES; ++w) {
         if (wid == w) {
 #pragma unroll

@@ -1,0 +1,200 @@
+// lin.h - Linear layers on fp32 MFMA (v_mfma_f32_16x16x4_f32) for skinny shapes.
+//
+// The Linear layers on this path have M = batch (thousands) but K, N in 15..288, so a classic
+// K-looped GEMM is latency-bound (a few k-steps of a few microseconds each on a handful of
+// blocks).  Instead each workgroup takes a 32-row x 32-column output tile and loads its WHOLE K
+// extent in one shot (every global load in flight at once: a single memory latency), then runs
+// the MFMA chain out of LDS.
+//
+//   lin_fwd_k   : C[b][n] (=|+=) act( sum_k A'[b][k] * W'(k,n) + bias[n] )
+//                 forward (A' = x, W'(k,n) = W[n][k]) and input gradient
+//                 (A' = dY * act'(Y) taken on load, W'(k,n) = W[k][n]).
+//   lin_wgrad_k : dW[n][k] += sum_b dY'[b][n] * X[b][k],  db[n] += sum_b dY'[b][n]
+//                 (K of the MFMA = batch); one atomicAdd per element and workgroup.
+#pragma once
+#include "common.h"
+#include "igemm.h"  // f32x4, FastDiv
+
+#define LIN_THREADS 256
+#define LIN_BM 32
+#define LIN_BN 32
+#define LIN_WS 33  // row stride of the [k][n] weight tile: conflict-free transposed fill
+
+struct LinArgs {
+    const float* A;   // [B][K], row stride lda
+    const float* A2;  // optional [B][K] (row stride lda2): A' = A * act'(A2)
+    const float* W;   // W'(k,n) at W[k*wsk + n*wsn]
+    const float* bias;
+    float* C;         // [B][N], row stride ldc
+    int lda, lda2, ldc;
+    int64_t wsk, wsn;
+    int B, K, N;
+    int KC;           // K extent staged per pass (multiple of 16); K is walked in ceil(K/KC) passes
+    int Kp;           // KC + 1: odd row stride of the A tile
+    int a_act, act, accumulate;
+    float a_slope, slope;
+    FastDiv d_KC;
+};
+
+__global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [32][Kp]
+    float* Ws = As + LIN_BM * a.Kp;    // [KC][33]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.x * LIN_BM, n0 = blockIdx.y * LIN_BN;
+
+    const int mt = wid >> 1, nt = wid & 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = As + (mt * 16 + li) * a.Kp + lk;
+    const float* wp = Ws + lk * LIN_WS + nt * 16 + li;
+    const int total = LIN_BM * a.KC;  // == LIN_BN * a.KC
+    const bool nfast = (a.wsn == 1);
+    for (int kc0 = 0; kc0 < a.K; kc0 += a.KC) {
+        if (kc0 > 0) __syncthreads();
+        for (int base = tid; base < total; base += LIN_THREADS * 8) {
+            float va[8], vw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = base + j * LIN_THREADS;
+                va[j] = 0.f;
+                vw[j] = 0.f;
+                if (e < total) {
+                    const int r = fdiv((uint32_t)e, a.d_KC), k = e - r * a.KC;
+                    if (m0 + r < a.B && kc0 + k < a.K) {
+                        va[j] = a.A[(int64_t)(m0 + r) * a.lda + kc0 + k];
+                        if (a.A2 != nullptr)
+                            va[j] *= act_grad_from_out(a.A2[(int64_t)(m0 + r) * a.lda2 + kc0 + k], a.a_act, a.a_slope);
+                    }
+                    // weight tile: walk the memory-contiguous index fastest
+                    const int wn = nfast ? (e & 31) : r, wk = nfast ? (e >> 5) : k;
+                    if (n0 + wn < a.N && kc0 + wk < a.K) vw[j] = a.W[(int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = base + j * LIN_THREADS;
+                if (e < total) {
+                    const int r = fdiv((uint32_t)e, a.d_KC), k = e - r * a.KC;
+                    As[r * a.Kp + k] = va[j];
+                    const int wn = nfast ? (e & 31) : r, wk = nfast ? (e >> 5) : k;
+                    Ws[wk * LIN_WS + wn] = vw[j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int k4 = 0; k4 < a.KC; k4 += 16) {
+            const float a0 = ap[k4], a1 = ap[k4 + 4], a2 = ap[k4 + 8], a3 = ap[k4 + 12];
+            const float b0 = wp[k4 * LIN_WS], b1 = wp[(k4 + 4) * LIN_WS], b2 = wp[(k4 + 8) * LIN_WS],
+                        b3 = wp[(k4 + 12) * LIN_WS];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+        }
+    }
+    // D: col = li, row = lk*4 + r
+    const int n = n0 + nt * 16 + li;
+    if (n >= a.N) return;
+    const float bv = a.bias != nullptr ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + lk * 4 + r;
+        if (m < a.B) {
+            float v = act_apply(acc[r] + bv, a.act, a.slope);
+            float* cp = a.C + (int64_t)m * a.ldc + n;
+            *cp = a.accumulate ? *cp + v : v;
+        }
+    }
+}
+
+// ---- weight / bias gradient ----------------------------------------------------------------
+#define LW_BB 64   // samples per staged chunk
+#define LW_YS 48   // row strides == 16 (mod 32): the four k-rows of an MFMA step hit disjoint banks
+#define LW_XS 80
+
+struct LinWgArgs {
+    const float* dY;  // [B][N] rows lddy
+    const float* Y;   // [B][N] rows ldy (for act'), may be null
+    const float* X;   // [B][K] rows ldx
+    float* dW;        // [N][K]
+    float* db;        // [N] or null
+    int lddy, ldy, ldx;
+    int B, N, K;
+    int act;
+    float slope;
+    int chunks_per_block;  // consecutive LW_BB-sample chunks handled by one workgroup
+};
+
+__global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgArgs a) {
+    __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+32)
+    __shared__ float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.z * 64;
+    const int nt = wid & 1, kt0 = (wid >> 1) * 2;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int c_first = blockIdx.x * a.chunks_per_block;
+    for (int ch = c_first; ch < c_first + a.chunks_per_block; ++ch) {
+        const int b0 = ch * LW_BB;
+        if (b0 >= a.B) break;
+        __syncthreads();
+        // stage: 64 rows x 32 dY' columns and 64 rows x 64 X columns, zero beyond the edges
+        float vy[8], vx[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + j * LIN_THREADS;  // 2048 = 64 x 32
+            const int r = e >> 5, c = e & 31;
+            float v = 0.f;
+            if (b0 + r < a.B && n0 + c < a.N) {
+                v = a.dY[(int64_t)(b0 + r) * a.lddy + n0 + c];
+                if (a.act != VAE_ACT_NONE) v *= act_grad_from_out(a.Y[(int64_t)(b0 + r) * a.ldy + n0 + c], a.act, a.slope);
+            }
+            vy[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + j * LIN_THREADS;  // 4096 = 64 x 64
+            const int r = e >> 6, c = e & 63;
+            vx[j] = (b0 + r < a.B && k0 + c < a.K) ? a.X[(int64_t)(b0 + r) * a.ldx + k0 + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + j * LIN_THREADS;
+            Ys[(e >> 5) * LW_YS + (e & 31)] = vy[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + j * LIN_THREADS;
+            Xs[(e >> 6) * LW_XS + (e & 63)] = vx[j];
+        }
+        __syncthreads();
+        if (a.db != nullptr && blockIdx.z == 0 && tid < 32) {
+            float t = 0.f;
+            for (int r = 0; r < LW_BB; ++r) t += Ys[r * LW_YS + tid];
+            bsum += t;
+        }
+        const float* yp = Ys + lk * LW_YS + nt * 16 + li;
+        const float* xp = Xs + lk * LW_XS + kt0 * 16 + li;
+#pragma unroll 4
+        for (int b4 = 0; b4 < LW_BB; b4 += 4) {
+            const float av = yp[b4 * LW_YS];
+            const float x0 = xp[b4 * LW_XS], x1 = xp[b4 * LW_XS + 16];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x1, acc1, 0, 0, 0);
+        }
+    }
+    if (a.db != nullptr && blockIdx.z == 0 && tid < 32 && n0 + tid < a.N) atomicAdd(&a.db[n0 + tid], bsum);
+    // D: row (n) = lk*4 + r, col (k) = li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + nt * 16 + lk * 4 + r;
+        const int k = k0 + kt0 * 16 + li;
+        if (n < a.N) {
+            if (k < a.K) atomicAdd(&a.dW[(int64_t)n * a.K + k], acc0[r]);
+            if (k + 16 < a.K) atomicAdd(&a.dW[(int64_t)n * a.K + k + 16], acc1[r]);
+        }
+    }
+}

@@ -7,13 +7,14 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "chan.h"
 #include "common.h"
 #include "conv.h"
 #include "elem.h"
-#include "gemm.h"
 #include "igemm.h"
+#include "lin.h"
 
 static thread_local char g_err[512] = "";
 void vae_set_error(const char* fmt, ...) {
@@ -239,7 +240,9 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 
 // ---- fused implicit-GEMM conv path (igemm.h) ------------------------------------------------
 #define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
-#define IG_MAX_GRID 512             // persistent workgroups: 2 per CU, each loops over its chunks
+#define IG_WG_MAX_GRID 256          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
+                                    // workgroups also keep the global atomics on dw/dbias rare
+#define IG_MAX_GRID 1024            // persistent workgroups (up to 4 per CU), each loops over its chunks
 
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
@@ -317,7 +320,7 @@ static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
         }
         c.ntaps = c.nkh * c.nkw;
         c.Kc = g.Cin * c.ntaps;
-        c.KcPad = (c.Kc + 3) & ~3;
+        c.KcPad = (c.Kc + 15) & ~15;  // the k-loop runs four MFMA steps per iteration
         c.toff = toff; c.woff = woff;
         c.d_ntaps = mk_fdiv(c.ntaps > 0 ? c.ntaps : 1);
         c.d_nkw = mk_fdiv(c.nkw > 0 ? c.nkw : 1);
@@ -336,19 +339,20 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
     fill_classes(g, cls, &wsum, &tsum);
     const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW;
-    const int fixed = wsum + tsum + 2 * g.Np + 8;
+    const int coef = 8 * (g.Cin + g.N) + g.Np + 8;
+    const int fixed = wsum + tsum + coef;
     int fit = (IG_LDS_BUDGET_FLOATS - fixed) / (per_in + per_out);
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1) {
-        sb = (B + 2047) / 2048;  // aim for >= 4 chunks per resident workgroup when the batch allows
+        sb = (B + 1023) / 1024;  // about one chunk per resident workgroup (3-4 per CU): one latency round
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
         if (sb > B) sb = B;
     }
     p.SB = sb;
     p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * per_out; p.lds_tab = tsum;
-    p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + 2 * g.Np;
+    p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + coef;
     // FastDiv exactness bound: n * d < 2^32 for every (n, d) pair the kernels divide
     const uint64_t nmax = (uint64_t)(p.lds_in > p.lds_out ? p.lds_in : p.lds_out) + wsum;
     if (nmax * (uint64_t)(g.Cin * g.H * g.W + g.N * g.OH * g.OW + 1) >= ((uint64_t)1 << 32)) p.SB = 0;
@@ -367,12 +371,12 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
     p.NKp = (Gc * KH * KW + 15) & ~15;
     const int T = (p.Mp / 16) * (p.NKp / 16);
     const int per_S = Sc * SH * SW, per_G = Gc * p.Hp * p.Wp, per_tab = 2 * SH * SW;
-    const int nred = Sc > Gc ? Sc : Gc;
+    const int nred = 8 * (Sc + Gc);
     int fit = (IG_LDS_BUDGET_FLOATS - nred - 16) / (per_S + per_G + per_tab);
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1 && p.Mp <= 32 && T <= WG_MAXT) {
-        sb = (B + 2047) / 2048;
+        sb = (B + 1023) / 1024;
         while (sb < fit && sb * (per_S + per_G) < T * 256) ++sb;  // room for the cross-wave reduction image
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
@@ -415,6 +419,7 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     a.nchunks = (c.B + p.SB - 1) / p.SB;
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
+    { const char* e = getenv("VAE_DBG_SKIPG"); a.dbg = e ? atoi(e) : 0; }
     const int grid = a.nchunks < IG_MAX_GRID ? a.nchunks : IG_MAX_GRID;
     const size_t bytes = (size_t)p.total * sizeof(float);
     if (a.g.Np > 16)
@@ -522,7 +527,8 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     wa.d_KK = mk_fdiv(g.KH * g.KW); wa.d_KW = mk_fdiv(g.KW);
     wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
     wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
-    hipLaunchKernelGGL(igemm_wgrad_k, dim3(wa.nchunks < IG_MAX_GRID ? wa.nchunks : IG_MAX_GRID), dim3(IG_THREADS),
+    { const char* e = getenv("VAE_DBG_SKIP"); wa.dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(igemm_wgrad_k, dim3(wa.nchunks < IG_WG_MAX_GRID ? wa.nchunks : IG_WG_MAX_GRID), dim3(IG_THREADS),
                        (size_t)wp.total * sizeof(float), c.s, wa);
     VAE_LAUNCH_CHECK("igemm_wgrad_k");
 
@@ -645,15 +651,17 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
 }
 
 // ---- linear ---------------------------------------------------------------------------------
-static int launch_gemm(const Ctx& c, GemmArgs a, int ksplit) {
-    if (a.M < 1 || a.N < 1 || a.K < 1) VAE_FAIL(VAE_EINVAL, "gemm: bad shape %dx%dx%d", a.M, a.N, a.K);
-    if (ksplit < 1) ksplit = 1;
-    a.kchunk = (int)ceil_div64(ceil_div64(a.K, ksplit), GEMM_BK) * GEMM_BK;
-    const int gz = (int)ceil_div64(a.K, a.kchunk);
-    if (gz > 1 && a.mode != GEMM_ATOMIC) VAE_FAIL(VAE_EINVAL, "gemm: split-K needs atomic mode");
-    dim3 grid((a.N + GEMM_BN - 1) / GEMM_BN, (a.M + GEMM_BM - 1) / GEMM_BM, gz);
-    hipLaunchKernelGGL(gemm_f32_mfma_k, grid, dim3(256), 0, c.s, a);
-    VAE_LAUNCH_CHECK("gemm_f32_mfma_k");
+static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
+    if (a.B < 1 || a.N < 1 || a.K < 1) VAE_FAIL(VAE_EINVAL, "%s: bad shape %dx%dx%d", what, a.B, a.N, a.K);
+    const int K16 = (a.K + 15) / 16 * 16;
+    const int passes = (K16 + 319) / 320;
+    a.KC = ((K16 + passes - 1) / passes + 15) / 16 * 16;
+    a.Kp = a.KC + 1;
+    a.d_KC = mk_fdiv((uint32_t)a.KC);
+    const size_t bytes = (size_t)(LIN_BM * a.Kp + a.KC * LIN_WS) * sizeof(float);
+    dim3 grid((a.B + LIN_BM - 1) / LIN_BM, (a.N + LIN_BN - 1) / LIN_BN);
+    hipLaunchKernelGGL(lin_fwd_k, grid, dim3(LIN_THREADS), bytes, c.s, a);
+    VAE_LAUNCH_CHECK(what);
     return VAE_OK;
 }
 
@@ -671,16 +679,17 @@ static int linear_forward(const Ctx& c, const vae_op& op) {
     if (rc) return rc;
     const int K = op.d[0], N = op.d[1], ldx = op.d[2], ldy = op.d[3];
     bool ok = true;
-    GemmArgs a;
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
     a.A = resolve(c, op.r[0], strided_extent(c.B, ldx, K), "linear.in", &ok);
     a.C = resolve(c, op.r[1], strided_extent(c.B, ldy, N), "linear.out", &ok);
-    a.Bm = resolve(c, op.r[4], (int64_t)N * K, "linear.w", &ok);
+    a.W = resolve(c, op.r[4], (int64_t)N * K, "linear.w", &ok);
     a.bias = resolve_opt(c, op.r[5], N, "linear.b", &ok);
     if (!ok) return VAE_EINVAL;
-    a.M = c.B; a.N = N; a.K = K;
-    a.sam = ldx; a.sak = 1; a.sbk = 1; a.sbn = K; a.scm = ldy;
-    a.act = op.act; a.slope = op.f[0]; a.mode = GEMM_STORE;
-    return launch_gemm(c, a, 1);
+    a.B = c.B; a.N = N; a.K = K;
+    a.lda = ldx; a.ldc = ldy; a.wsk = 1; a.wsn = K;
+    a.act = op.act; a.slope = op.f[0];
+    return launch_lin(c, a, "lin_fwd_k(fwd)");
 }
 
 static int linear_backward(const Ctx& c, const vae_op& op) {
@@ -692,45 +701,37 @@ static int linear_backward(const Ctx& c, const vae_op& op) {
     const float* x = resolve(c, op.r[0], strided_extent(c.B, ldx, K), "linear.in", &ok);
     const float* y = resolve(c, op.r[1], strided_extent(c.B, ldy, N), "linear.out", &ok);
     float* dx = resolve_opt(c, op.r[2], strided_extent(c.B, lddx, K), "linear.din", &ok);
-    float* dy = resolve(c, op.r[3], strided_extent(c.B, lddy, N), "linear.dout", &ok);
+    const float* dy = resolve(c, op.r[3], strided_extent(c.B, lddy, N), "linear.dout", &ok);
     const float* w = resolve(c, op.r[4], (int64_t)N * K, "linear.w", &ok);
     float* dw = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), (int64_t)N * K, "linear.dw", &ok);
     float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), N, "linear.db", &ok);
-    float* part = resolve(c, op.r[6], (int64_t)2 * N * VAE_MAX_CHUNKS, "linear.partials", &ok);
     if (!ok) return VAE_EINVAL;
 
-    // 1) activation backward in place + bias gradient (column sums)
-    if (op.act != VAE_ACT_NONE || db != nullptr) {
-        int bchunk, nchunks;
-        chunking(c.B, 64, &bchunk, &nchunks);
-        hipLaunchKernelGGL(col_actbwd_reduce_k, dim3((N + 63) / 64, nchunks), dim3(256), 0, c.s, dy, y, part, c.B, N,
-                           lddy, ldy, bchunk, op.act, op.f[0]);
-        VAE_LAUNCH_CHECK("col_actbwd_reduce_k");
-        if (db != nullptr) {
-            hipLaunchKernelGGL(bias_grad_finalize_k, dim3((N + 63) / 64), dim3(64), 0, c.s, part, db, N, nchunks);
-            VAE_LAUNCH_CHECK("bias_grad_finalize_k");
-        }
-    }
-    // 2) dW[N][K] += dY^T X   (reduction over the batch: split-K + atomics into the zeroed grad)
-    GemmArgs a;
-    a.A = dy; a.Bm = x; a.C = dw; a.bias = nullptr;
-    a.M = N; a.N = K; a.K = c.B;
-    a.sam = 1; a.sak = lddy; a.sbk = ldx; a.sbn = 1; a.scm = K;
-    a.act = VAE_ACT_NONE; a.slope = 0.f; a.mode = GEMM_ATOMIC;
-    const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
-    int ksplit = (int)ceil_div64(512, tiles);
-    const int max_split = (int)ceil_div64(c.B, 256);
-    if (ksplit > max_split) ksplit = max_split;
-    rc = launch_gemm(c, a, ksplit);
-    if (rc) return rc;
-    // 3) dX[B][K] (=|+=) dY W
+    // 1) dW[N][K] += (dY*act')^T X and db[N] += colsum(dY*act'): batch-chunked MFMA, atomics into the zeroed grads
+    LinWgArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.dY = dy; wa.Y = y; wa.X = x; wa.dW = dw; wa.db = db;
+    wa.lddy = lddy; wa.ldy = ldy; wa.ldx = ldx;
+    wa.B = c.B; wa.N = N; wa.K = K; wa.act = op.act; wa.slope = op.f[0];
+    const int tiles = ((N + 31) / 32) * ((K + 63) / 64);
+    const int nch = (c.B + LW_BB - 1) / LW_BB;
+    int gx = (1024 + tiles - 1) / tiles;  // aim at ~1024 workgroups
+    if (gx > nch) gx = nch;
+    wa.chunks_per_block = (nch + gx - 1) / gx;
+    gx = (nch + wa.chunks_per_block - 1) / wa.chunks_per_block;
+    hipLaunchKernelGGL(lin_wgrad_k, dim3(gx, (N + 31) / 32, (K + 63) / 64), dim3(LIN_THREADS), 0, c.s, wa);
+    VAE_LAUNCH_CHECK("lin_wgrad_k");
+    // 2) dX[B][K] (=|+=) (dY*act') W
     if (dx != nullptr) {
-        GemmArgs b;
-        b.A = dy; b.Bm = w; b.C = dx; b.bias = nullptr;
-        b.M = c.B; b.N = K; b.K = N;
-        b.sam = lddy; b.sak = 1; b.sbk = K; b.sbn = 1; b.scm = lddx;
-        b.act = VAE_ACT_NONE; b.slope = 0.f; b.mode = (op.flags & VAE_F_ACC_DIN) ? GEMM_ACCUM : GEMM_STORE;
-        rc = launch_gemm(c, b, 1);
+        LinArgs b;
+        memset(&b, 0, sizeof(b));
+        b.A = dy; b.lda = lddy;
+        if (op.act != VAE_ACT_NONE) { b.A2 = y; b.lda2 = ldy; b.a_act = op.act; b.a_slope = op.f[0]; }
+        b.W = w; b.wsk = K; b.wsn = 1;
+        b.C = dx; b.ldc = lddx;
+        b.B = c.B; b.N = K; b.K = N;
+        b.accumulate = (op.flags & VAE_F_ACC_DIN) ? 1 : 0;
+        rc = launch_lin(c, b, "lin_fwd_k(dgrad)");
     }
     return rc;
 }
