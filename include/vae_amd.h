@@ -121,6 +121,9 @@ int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const in
 /* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
  * the Python program builder; no GPU needed). */
 int vae_conv_fused_ok(const vae_op* op, int B);
+/* Floats of shared scratch (the op's r[6] slot) a FUSED CONV/CONVT op needs at batch B: the larger of
+ * its BatchNorm statistic slabs and the per-workgroup weight-gradient partials.  0 if not fusable. */
+int64_t vae_conv_scratch_floats(const vae_op* op, int B);
 
 /* Standalone criterion (autograd path).  Replaces train.py:39-48 / notebook :141-151.
  * out: 3 floats (loss, recon, kld).  partials: >= 2*VAE_ELBO_BLOCKS floats of scratch.

@@ -49,6 +49,8 @@ def lib():
     L.vae_run_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp]
     L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
     L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
+    L.vae_conv_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
+    L.vae_conv_scratch_floats.restype = i64
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_elbo_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]
@@ -65,7 +67,7 @@ def lib():
     return L
 
 
-EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
+EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_scratch_floats", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
            "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 

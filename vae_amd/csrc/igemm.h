@@ -95,7 +95,7 @@ struct IgArgs {
     // LDS carve (floats)
     int lds_in, lds_w, lds_out, lds_tab;
     int ncls, nchunks;
-    int dbg;  // ablation mask (VAE_DBG_SKIPG env, diagnostics only)
+    int dbgp;
     FastDiv d_N, d_ntile;  // by N and by Np/16
     IgClass cls[4];
 };
@@ -141,7 +141,7 @@ __device__ __forceinline__ void ig_load_coef(const float* g, float* l, int n) {
         for (int i = threadIdx.x; i < n; i += IG_THREADS) l[i] = g[i];
 }
 
-template <int NT>
+template <int NT, int TI>
 __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
@@ -158,15 +158,14 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     const int HpWp = g.Hp * g.Wp, CinHpWp = g.Cin * HpWp;
     const int OHW = g.OH * g.OW;
     const int n_ntile = g.Np >> 4;
-    if (a.dbg & 32) return;
 
+    long long T0 = wall_clock64(), Tst = 0, Tti = 0, Tco = 0, Tsetup, t1, t2;
     // ---- once per workgroup: clear the input image (the halo must read as zero and is never
     // written again), build the tap-offset tables and the [k][n] weight images of every class
     for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
     ig_load_coef(a.in.coef, cin, 8 * g.Cin);
     ig_load_coef(a.ep_coef, cep, 8 * g.N);
     for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
-    if (!(a.dbg & 8))
     for (int cls = 0; cls < a.ncls; ++cls) {
         const IgClass& c = a.cls[cls];
         const int nw = c.KcPad * g.Np;
@@ -192,65 +191,84 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
         }
     }
 
+    Tsetup = wall_clock64() - T0;
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        t1 = wall_clock64();
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
         __syncthreads();  // previous chunk's copy-out is done with lout; tables/coefficients are ready
-        if (!(a.dbg & 1))
         ig_stage(a.in, cin, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h,
                  g.halo_w, g.d_CHW, g.d_HW, g.d_W);
         __syncthreads();
+        t2 = wall_clock64(); Tst += t2 - t1; t1 = t2;
 
         // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
         int tile_base = 0;
-        if (!(a.dbg & 2))
         for (int cls = 0; cls < a.ncls; ++cls) {
             const IgClass& c = a.cls[cls];
             const int AHW = c.AH * c.AW;
             const int P = sb * AHW;
             const int ntile = (P + 15) >> 4;
-            for (int t = (wid + IG_WAVES - (tile_base & (IG_WAVES - 1))) & (IG_WAVES - 1); t < ntile; t += IG_WAVES) {
-                const int q = t * 16 + li;
-                const bool valid = q < P;
-                const int qq = valid ? q : 0;
-                const int s = fdiv((uint32_t)qq, c.d_AHW), rem = qq - s * AHW;
-                const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
-                const float* lp = lin + s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
-                const int outoff = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
+            // TI tiles in flight per wave: their table -> gather -> MFMA -> store chains are independent,
+            // which is what hides the LDS and MFMA latencies (the kernels are latency-, not issue-bound)
+            for (int t0 = (wid + IG_WAVES - (tile_base & (IG_WAVES - 1))) & (IG_WAVES - 1); t0 < ntile;
+                 t0 += IG_WAVES * TI) {
+                const float* lp[TI];
+                int outoff[TI];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int q = (t0 + i * IG_WAVES) * 16 + li;
+                    const bool valid = q < P;
+                    const int qq = valid ? q : 0;
+                    const int s = fdiv((uint32_t)qq, c.d_AHW), rem = qq - s * AHW;
+                    const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
+                    lp[i] = lin + s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
+                    outoff[i] = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
+                }
                 const int* kt = ktab + c.toff + lk;
                 for (int nc = 0; nc < n_ntile; nc += NT) {
-                    f32x4 acc[NT];
-                    float bias_r[NT];
+                    f32x4 acc[TI][NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        bias_r[j] = (nc + j < n_ntile) ? lbias[(nc + j) * 16 + li] : 0.f;
-                    }
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < TI; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const float* lwc = lw + c.woff + lk * g.Np + nc * 16 + li;
-                    // KcPad is a multiple of 16: four independent k-steps per iteration so that the
-                    // table read -> gather read -> MFMA chains of different steps overlap
+                    // KcPad is a multiple of 16: four independent k-steps per iteration
                     for (int k4 = 0; k4 < c.KcPad; k4 += 16) {
                         const int o0 = kt[k4], o1 = kt[k4 + 4], o2 = kt[k4 + 8], o3 = kt[k4 + 12];
-                        const float a0 = lp[o0], a1 = lp[o1], a2 = lp[o2], a3 = lp[o3];
+                        float av[TI][4], bw[NT][4];
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            if (nc + j < n_ntile) {
-                                const float* wj = lwc + k4 * g.Np + j * 16;
-                                const float b0 = wj[0], b1 = wj[4 * g.Np], b2 = wj[8 * g.Np], b3 = wj[12 * g.Np];
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[j], 0, 0, 0);
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[j], 0, 0, 0);
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc[j], 0, 0, 0);
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc[j], 0, 0, 0);
-                            }
-                    }
-                    // D: col (channel) = li, row (pixel) = lk*4 + r
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int oo = __shfl(outoff, lk * 4 + r, 64);
+                        for (int i = 0; i < TI; ++i) {
+                            av[i][0] = lp[i][o0]; av[i][1] = lp[i][o1]; av[i][2] = lp[i][o2]; av[i][3] = lp[i][o3];
+                        }
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            const int n = (nc + j) * 16 + li;
-                            if (oo >= 0 && n < g.N) lout[oo + n * OHW] = acc[j][r] + bias_r[j];
+                            // (a padding channel tile reads finite weights of the next class / table: harmless)
+                            const float* wj = lwc + k4 * g.Np + (nc + j < n_ntile ? j * 16 : 0);
+                            bw[j][0] = wj[0]; bw[j][1] = wj[4 * g.Np]; bw[j][2] = wj[8 * g.Np]; bw[j][3] = wj[12 * g.Np];
+                        }
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+#pragma unroll
+                            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                                for (int j = 0; j < NT; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j][h], av[i][h], acc[i][j], 0, 0, 0);
+                    }
+                    // A = weights, B = pixels: D row (channel) = lk*4 + r, col (pixel) = li, so every lane
+                    // stores the four channels of its own pixel (no cross-lane traffic in the epilogue)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int n0 = (nc + j) * 16 + lk * 4;
+                        if (n0 < g.N) {  // (false for a whole padding tile: n0 >= Np)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float bv = lbias[n0 + r];
+#pragma unroll
+                                for (int i = 0; i < TI; ++i)
+                                    if (outoff[i] >= 0 && n0 + r < g.N)
+                                        lout[outoff[i] + (n0 + r) * OHW] = acc[i][j][r] + bv;
+                            }
                         }
                     }
                 }
@@ -258,15 +276,16 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
             tile_base += ntile;
         }
         __syncthreads();
+        t2 = wall_clock64(); Tti += t2 - t1; t1 = t2;
 
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
         const int64_t obase = (int64_t)s0 * g.N * OHW;
         const int total = sb * g.N * OHW;
-        if (a.dbg & 4) continue;
         if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
             // (the activation runs here, once per real output element with every lane busy, not in the
             // MFMA epilogue where 15 of 16 lanes may hold padding channels)
             for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
+            t2 = wall_clock64(); Tco += t2 - t1;
             continue;
         }
         // one wave per channel: it walks that channel's row in every sample of the chunk, so the two
@@ -315,7 +334,10 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
                 }
             }
         }
+        t2 = wall_clock64(); Tco += t2 - t1;
     }
+    if (a.dbgp && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+        printf("gather<%d,%d> blk %d: setup %lld stage %lld tiles %lld copyout %lld total %lld (x10ns) SB %d nchunks %d grid %d ep %d slab %d\n", NT, TI, blockIdx.x, Tsetup, Tst, Tti, Tco, wall_clock64() - T0, a.SB, a.nchunks, gridDim.x, a.ep_mode, a.slab != nullptr);
 }
 
 // ---- weight gradient --------------------------------------------------------------------------
@@ -330,159 +352,205 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
 
 struct WgArgs {
     TensorIn S, G;
-    float* dw;
-    float* dbias;     // bias gradient or nullptr
+    float* part;      // [gridDim.x][MT*NT*256 + 64] workgroup partials (reduced by wgrad_finalize_k)
+    int want_bias;
+    int dbgp;
     int bias_from_S;  // 1: dbias from S (Conv), 0: from G (ConvT)
     int B, SB, nchunks;
     int Sc, SH, SW;   // S: channels, small grid
     int Gc, GH, GW;   // G: channels, big grid
     int KH, KW, sh, sw, ph, pw;
     int Hp, Wp;       // padded G image (halo = ph, pw low side)
-    int Mp, NKp;      // Sc and Gc*KH*KW rounded up to 16
-    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW;
+    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW, d_bC;
     int lds_S, lds_G, lds_tab;
-    int dbg;  // ablation mask (VAE_DBG_SKIP env, diagnostics only)
 };
 
+// MT x NT accumulator tiles (16x16 each) per wave: compile-time so that every operand read of a step
+// is issued before its first MFMA and the loop has no branches.  Rows m >= Sc and columns
+// n >= Gc*KH*KW read a clamped (valid) row/column; their results are simply never written.
+template <int MT, int NT>
 __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lS = smem;                 // [sb][Sc][SHW]
     float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]
-    int* ptab = reinterpret_cast<int*>(lG + a.lds_G);  // per pixel: (S offset, G base)
+    int2* ptab = reinterpret_cast<int2*>(lG + a.lds_G);  // per pixel: (S offset, G base)
     float* cS = reinterpret_cast<float*>(ptab + a.lds_tab);  // [8*Sc] transform coefficients of S
     float* cG = cS + 8 * a.Sc;                                // [8*Gc] ... of G
+    float* bred = cG + 8 * a.Gc;                              // [IG_WAVES][64] bias partials
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int SHW = a.SH * a.SW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW;
     const int NK = a.Gc * KK;
     const int Pfull = a.SB * SHW;
-    if (a.dbg & 32) return;
 
-    if (!(a.dbg & 64))
+    long long T0 = wall_clock64(), Tst = 0, Tbi = 0, Tmf = 0, Tsetup, Tloop, t1, t2;
     for (int i = tid; i < a.lds_G; i += IG_THREADS) lG[i] = 0.f;  // halo stays zero for every chunk
     ig_load_coef(a.S.coef, cS, 8 * a.Sc);
     ig_load_coef(a.G.coef, cG, 8 * a.Gc);
     // pixel table (same for every chunk): q -> S offset (s*Sc*SHW + pix), G base (s*Gc*HpWp + oh*sh*Wp + ow*sw)
-    if (!(a.dbg & 128))
-    for (int q = tid; q < ((Pfull + 3) & ~3); q += IG_THREADS) {
-        int so = 0, gb = 0;
-        if (q < Pfull) {
-            const int s = fdiv((uint32_t)q, a.dS_HW), pix = q - s * SHW;
-            const int oh = fdiv((uint32_t)pix, a.dS_W), ow = pix - oh * a.SW;
-            so = s * a.Sc * SHW + pix;
-            gb = s * a.Gc * HpWp + oh * a.sh * a.Wp + ow * a.sw;
-        }
-        ptab[2 * q] = so;
-        ptab[2 * q + 1] = gb;
+    for (int q = tid; q < Pfull; q += IG_THREADS) {
+        const int s = fdiv((uint32_t)q, a.dS_HW), pix = q - s * SHW;
+        const int oh = fdiv((uint32_t)pix, a.dS_W), ow = pix - oh * a.SW;
+        ptab[q] = make_int2(s * a.Sc * SHW + pix, s * a.Gc * HpWp + oh * a.sh * a.Wp + ow * a.sw);
     }
 
-    const int MT = a.Mp >> 4, NTt = a.NKp >> 4, T = MT * NTt;
-    // per-lane constants: B column n = nt*16 + li -> tap offset in the G image
-    int koffN[WG_MAXT];
-    f32x4 acc[WG_MAXT];
-    bool nvalid[WG_MAXT];
+    // per-lane constants: A row m = mt*16 + li -> channel offset in the S image;
+    // B column n = nt*16 + li -> (channel, tap) offset in the G image
+    int moff[MT], koffN[NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int nt = 0; nt < WG_MAXT; ++nt) {
-        acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        koffN[nt] = 0;
-        nvalid[nt] = false;
-        if (nt < NTt) {
-            const int n = nt * 16 + li;
-            if (n < NK) {
-                const int c = fdiv((uint32_t)n, a.d_KK), tap = n - c * KK;
-                const int kh = fdiv((uint32_t)tap, a.d_KW), kw = tap - kh * a.KW;
-                koffN[nt] = c * HpWp + kh * a.Wp + kw;
-                nvalid[nt] = true;
-            }
-        }
+    for (int mt = 0; mt < MT; ++mt) moff[mt] = min(mt * 16 + li, a.Sc - 1) * SHW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(nt * 16 + li, NK - 1);
+        const int c = fdiv((uint32_t)n, a.d_KK), tap = n - c * KK;
+        const int kh = fdiv((uint32_t)tap, a.d_KW), kw = tap - kh * a.KW;
+        koffN[nt] = c * HpWp + kh * a.Wp + kw;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    float bsum = 0.f;  // lane 0 of wave w: bias partial of the channels that wave owns
+    float bsum = 0.f;  // lane c of every wave: this wave's share of the bias gradient of channel c (< 64)
 
+    Tsetup = wall_clock64() - T0;
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        t1 = wall_clock64();
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
         const int P = sb * SHW;
-        const int Ppad = (P + 3) & ~3;
         __syncthreads();  // tables ready / previous chunk's MFMAs are done with the tiles
-        if (!(a.dbg & 1))
         ig_stage(a.S, cS, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW,
                  a.dS_W);
-        if (!(a.dbg & 2))
         ig_stage(a.G, cG, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
                  a.dG_CHW, a.dG_HW, a.dG_W);
         __syncthreads();
-        // bias gradient: channel c is owned by wave (c % IG_WAVES); at most 4 channels per wave here
-        if (a.dbias != nullptr && !(a.dbg & 16)) {
+        t2 = wall_clock64(); Tst += t2 - t1; t1 = t2;
+        // bias gradient = per-channel sum of the d(pre-activation) image (its zero halo adds nothing):
+        // the (sample, channel) rows go round-robin over the waves
+        if (a.want_bias) {
             const float* img = a.bias_from_S ? lS : lG;
             const int C = a.bias_from_S ? a.Sc : a.Gc;
             const int rowlen = a.bias_from_S ? SHW : HpWp;
-            for (int c = wid, slot = 0; c < C; c += IG_WAVES, ++slot) {
+            for (int u = wid; u < sb * C; u += IG_WAVES) {
+                const float* row = img + u * rowlen;
                 float t = 0.f;
-                for (int s = 0; s < sb; ++s)
-                    for (int i = lane; i < rowlen; i += 64) t += img[(s * C + c) * rowlen + i];
+                for (int i = lane; i < rowlen; i += 64) t += row[i];
                 t = wave_sum_all(t);
-                if (lane == slot) bsum += t;  // lane `slot` of this wave accumulates channel wid + slot*IG_WAVES
+                const int c = u - (int)fdiv((uint32_t)u, a.d_bC) * C;
+                if (lane == c) bsum += t;
             }
         }
-        // pixels: wave w takes steps w, w+IG_WAVES, ... (4 pixels per MFMA step)
-        if (!(a.dbg & 4))
-        for (int q4 = wid * 4; q4 < Ppad; q4 += 4 * IG_WAVES) {
-            const int q = q4 + lk;
-            const bool qv = q < P;
-            const int so = ptab[2 * q], gb = ptab[2 * q + 1];
-            float av[2];
+        t2 = wall_clock64(); Tbi += t2 - t1; t1 = t2;
+        // pixels: four per MFMA step, two independent steps per iteration, steps round-robin over the waves
+        for (int q4 = wid * 4; q4 < P; q4 += 8 * IG_WAVES) {
+            const int qa = q4 + lk, qb = qa + 4 * IG_WAVES;
+            const bool va = qa < P, vb = qb < P;
+            const int2 pa = ptab[va ? qa : 0], pb = ptab[vb ? qb : 0];
+            float av[2][MT], bv[2][NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                av[mt] = (mt < MT && mt * 16 + li < a.Sc && qv) ? lS[so + (mt * 16 + li) * SHW] : 0.f;
-#pragma unroll
-            for (int nt = 0; nt < WG_MAXT; ++nt) {
-                if (nt < NTt) {
-                    const float bv = (nvalid[nt] && qv) ? lG[gb + koffN[nt]] : 0.f;
-                    if (MT == 1) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[nt], 0, 0, 0);
-                    else if (2 * nt + 1 < WG_MAXT) {
-                        acc[2 * nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[2 * nt], 0, 0, 0);
-                        acc[2 * nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv, acc[2 * nt + 1], 0, 0, 0);
-                    }
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                av[0][mt] = lS[pa.x + moff[mt]];
+                av[1][mt] = lS[pb.x + moff[mt]];
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bv[0][nt] = lG[pa.y + koffN[nt]];
+                bv[1][nt] = lG[pb.y + koffN[nt]];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {  // pixels past the chunk: zero A column, finite B
+                av[0][mt] = va ? av[0][mt] : 0.f;
+                av[1][mt] = vb ? av[1][mt] : 0.f;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][mt], bv[h][nt], acc[mt][nt], 0, 0, 0);
         }
+        t2 = wall_clock64(); Tmf += t2 - t1;
     }
     __syncthreads();
-    if (a.dbias != nullptr) {  // gather the per-wave partials in LDS: ONE atomic wave-instruction per workgroup
-        const int C = a.bias_from_S ? a.Sc : a.Gc;
-        const int c = wid + lane * IG_WAVES;
-        if (lane < 8 && c < C) smem[c] = bsum;
-        __syncthreads();
-        if (tid < C) atomicAdd(&a.dbias[tid], smem[tid]);
-        __syncthreads();
-    }
-    // cross-wave reduction through LDS: waves add their tiles in turn into rbuf[T][4][64]
-    // (overlays the S/G tiles, which are dead now; the host sizes lds_S + lds_G >= T*256)
-    float* rbuf = smem;
-    if (a.dbg & 8) return;
-    for (int w = 0; w < IG_WAVES; ++w) {
-        if (wid == w) {
+    Tloop = wall_clock64() - T0;
+    // cross-wave reduction in LDS (rbuf overlays the dead S/G tiles; the host sizes them >= MT*NT*256);
+    // the workgroup's partial goes to its own row of `part` in accumulator-tile order, bias sums behind it
+    // (global atomics on the few cache lines of dw serialise in L2 and cost more than the whole MFMA loop)
+    constexpr int TE = MT * NT * 256;
+    constexpr int TPT = (TE + IG_THREADS - 1) / IG_THREADS;
+    const int nw = min(IG_WAVES, (a.lds_S + a.lds_G) / TE);  // waves whose tiles fit in LDS at once (>= 1)
+    float tot[TPT];
 #pragma unroll
-            for (int t = 0; t < WG_MAXT; ++t)
-                if (t < T) {
+    for (int k = 0; k < TPT; ++k) tot[k] = 0.f;
+    bred[wid * 64 + lane] = bsum;
+    for (int w0 = 0; w0 < IG_WAVES; w0 += nw) {
+        if (wid >= w0 && wid < w0 + nw) {
+            float* slot = smem + (wid - w0) * TE;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = &rbuf[(t * 4 + r) * 64 + lane];
-                        *p = (w == 0 ? 0.f : *p) + acc[t][r];
-                    }
-                }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slot[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        const int cnt = min(nw, IG_WAVES - w0);
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int i = tid + k * IG_THREADS;
+            if (i < TE)
+                for (int w = 0; w < cnt; ++w) tot[k] += smem[w * TE + i];
         }
         __syncthreads();
     }
-    for (int i = tid; i < T * 256; i += IG_THREADS) {
-        const int t = i >> 8, r = (i >> 6) & 3, l = i & 63;
-        int mt, nt;
-        if (MT == 1) { mt = 0; nt = t; }
-        else { nt = t >> 1; mt = t & 1; }
-        const int m = mt * 16 + (l >> 4) * 4 + r;  // D row
-        const int n = nt * 16 + (l & 15);          // D col
-        if (m < a.Sc && n < NK) atomicAdd(&a.dw[(int64_t)m * NK + n], rbuf[i]);
+    float* row = a.part + (int64_t)blockIdx.x * (TE + 64);
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+        const int i = tid + k * IG_THREADS;
+        if (i < TE) row[i] = tot[k];
+    }
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < IG_WAVES; ++w) t += bred[w * 64 + tid];
+        row[MT * NT * 256 + tid] = t;
+    }
+    if (a.dbgp && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+        printf("wgrad<%d,%d> blk %d: setup %lld stage %lld bias %lld mfma %lld loop_end %lld total %lld (x10ns) SB %d nchunks %d\n", MT, NT, blockIdx.x, Tsetup, Tst, Tbi, Tmf, Tloop, wall_clock64() - T0, a.SB, a.nchunks);
+}
+
+// Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias.  One workgroup per 32
+// partial columns; its 8 slices stride over the partial rows (128-byte coalesced reads).
+__global__ __launch_bounds__(256) void wgrad_finalize_k(const float* __restrict__ part, int nrows, int NT, int T,
+                                                        int Sc, int NK, float* __restrict__ dw,
+                                                        float* __restrict__ dbias, int C) {
+    __shared__ float red[8][32];
+    const int stride = T * 256 + 64;
+    const int jj = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jj;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = slice;
+    for (; b + 24 < nrows; b += 32) {
+        t0 += part[(int64_t)b * stride + j];
+        t1 += part[(int64_t)(b + 8) * stride + j];
+        t2 += part[(int64_t)(b + 16) * stride + j];
+        t3 += part[(int64_t)(b + 24) * stride + j];
+    }
+    for (; b < nrows; b += 8) t0 += part[(int64_t)b * stride + j];
+    red[slice][jj] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (slice != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][jj];
+    if (j < T * 256) {
+        const int tile = j >> 8, r = (j >> 6) & 3, l = j & 63;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const int m = mt * 16 + (l >> 4) * 4 + r, n = nt * 16 + (l & 15);
+        if (m < Sc && n < NK) dw[(int64_t)m * NK + n] += t;
+    } else if (dbias != nullptr && j - T * 256 < C) {
+        dbias[j - T * 256] += t;
     }
 }
 

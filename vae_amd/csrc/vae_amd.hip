@@ -239,10 +239,14 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 
 
 // ---- fused implicit-GEMM conv path (igemm.h) ------------------------------------------------
-#define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
-#define IG_WG_MAX_GRID 256          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
+static int tune(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define IG_LDS_BUDGET_FLOATS tune("VAE_T_LDS", 16000)  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
+#define IG_WG_LDS_BUDGET tune("VAE_T_WGLDS", 16000)
+#define IG_WG_MAX_GRID tune("VAE_T_WGGRID", 256)          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
                                     // workgroups also keep the global atomics on dw/dbias rare
-#define IG_MAX_GRID 1024            // persistent workgroups (up to 4 per CU), each loops over its chunks
+#define IG_MAX_GRID tune("VAE_T_GRID", 512)            // persistent workgroups (up to 4 per CU), each loops over its chunks
+#define IG_SB_TARGET tune("VAE_T_SBT", 1024)
+#define IG_WG_SB_TARGET tune("VAE_T_WGSBT", 1024)
 
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
@@ -345,7 +349,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1) {
-        sb = (B + 1023) / 1024;  // about one chunk per resident workgroup (3-4 per CU): one latency round
+        sb = (B + IG_SB_TARGET - 1) / IG_SB_TARGET;  // about one chunk per resident workgroup (3-4 per CU): one latency round
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
         if (sb > B) sb = B;
@@ -360,23 +364,32 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
 }
 
 struct WgPlan {
-    int SB, lds_S, lds_G, lds_tab, total, Hp, Wp, Mp, NKp;
+    int SB, lds_S, lds_G, lds_tab, total, Hp, Wp, MT, NT;
 };
+// accumulator-tile buckets igemm_wgrad_k is instantiated for (MT x NT tiles of 16x16 per wave)
+static int wgrad_bucket(int Sc, int NK, int* MT, int* NT) {
+    static const int nts[] = {1, 2, 3, 5, 10};
+    const int mt = (Sc + 15) / 16, ntt = (NK + 15) / 16;
+    if (mt > 2) return 0;
+    for (int nt : nts)
+        if (nt >= ntt && !(mt == 2 && (nt == 1 || nt == 3))) { *MT = mt; *NT = nt; return 1; }
+    return 0;
+}
 static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, int KH, int KW, int sh, int sw, int ph,
                          int pw) {
     WgPlan p;
+    memset(&p, 0, sizeof(p));
     p.Hp = (SH - 1) * sh + KH; if (p.Hp < GH + ph) p.Hp = GH + ph;
     p.Wp = (SW - 1) * sw + KW; if (p.Wp < GW + pw) p.Wp = GW + pw;
-    p.Mp = (Sc + 15) & ~15;
-    p.NKp = (Gc * KH * KW + 15) & ~15;
-    const int T = (p.Mp / 16) * (p.NKp / 16);
+    if (!wgrad_bucket(Sc, Gc * KH * KW, &p.MT, &p.NT) || Gc > 64) return p;
+    const int T = p.MT * p.NT;
     const int per_S = Sc * SH * SW, per_G = Gc * p.Hp * p.Wp, per_tab = 2 * SH * SW;
-    const int nred = 8 * (Sc + Gc);
-    int fit = (IG_LDS_BUDGET_FLOATS - nred - 16) / (per_S + per_G + per_tab);
+    const int nred = 8 * (Sc + Gc) + IG_WAVES * 64;
+    int fit = (IG_WG_LDS_BUDGET - nred - 16) / (per_S + per_G + per_tab);
     if (fit > 64) fit = 64;
     int sb = 0;
-    if (fit >= 1 && p.Mp <= 32 && T <= WG_MAXT) {
-        sb = (B + 1023) / 1024;
+    if (fit >= 1) {
+        sb = (B + IG_WG_SB_TARGET - 1) / IG_WG_SB_TARGET;
         while (sb < fit && sb * (per_S + per_G) < T * 256) ++sb;  // room for the cross-wave reduction image
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
@@ -386,10 +399,44 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
     p.SB = sb;
     p.lds_S = sb * per_S; p.lds_G = sb * per_G;
     if (p.lds_S + p.lds_G < T * 256) p.lds_G = T * 256 - p.lds_S;  // tiny batches: pad the G region
-    p.lds_tab = ((sb * SH * SW + 3) & ~3) * 2;
-    p.total = p.lds_S + p.lds_G + p.lds_tab + nred + 8;
-    if (p.total > IG_LDS_BUDGET_FLOATS) p.SB = 0;
+    if ((p.lds_S + p.lds_G) & 1) ++p.lds_G;                        // the pixel table is int2: keep it 8-byte aligned
+    p.lds_tab = sb * SH * SW;                                      // int2 entries
+    p.total = p.lds_S + p.lds_G + 2 * p.lds_tab + nred + 8;
+    if (p.total > IG_WG_LDS_BUDGET) p.SB = 0;
     return p;
+}
+
+template <int MT, int NT>
+static void launch_wgrad_inst(const Ctx& c, const WgArgs& wa, int grid, size_t bytes) {
+    hipLaunchKernelGGL((igemm_wgrad_k<MT, NT>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
+}
+static int wgrad_grid(int nchunks) {
+    const int wg_max = IG_WG_MAX_GRID;
+    return nchunks < wg_max ? nchunks : wg_max;
+}
+static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
+    return (int64_t)wgrad_grid((B + wp.SB - 1) / wp.SB) * (wp.MT * wp.NT * 256 + 64);
+}
+static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float* dw, float* db) {
+    const int grid = wgrad_grid(wa.nchunks);
+    const size_t bytes = (size_t)wp.total * sizeof(float);
+    switch (wp.MT * 100 + wp.NT) {
+        case 101: launch_wgrad_inst<1, 1>(c, wa, grid, bytes); break;
+        case 102: launch_wgrad_inst<1, 2>(c, wa, grid, bytes); break;
+        case 103: launch_wgrad_inst<1, 3>(c, wa, grid, bytes); break;
+        case 105: launch_wgrad_inst<1, 5>(c, wa, grid, bytes); break;
+        case 110: launch_wgrad_inst<1, 10>(c, wa, grid, bytes); break;
+        case 202: launch_wgrad_inst<2, 2>(c, wa, grid, bytes); break;
+        case 205: launch_wgrad_inst<2, 5>(c, wa, grid, bytes); break;
+        case 210: launch_wgrad_inst<2, 10>(c, wa, grid, bytes); break;
+        default: VAE_FAIL(VAE_EINVAL, "conv wgrad: no kernel for %dx%d accumulator tiles", wp.MT, wp.NT);
+    }
+    VAE_LAUNCH_CHECK("igemm_wgrad_k");
+    const int T = wp.MT * wp.NT;
+    hipLaunchKernelGGL(wgrad_finalize_k, dim3(T * 8 + 2), dim3(256), 0, c.s, wa.part, grid, wp.NT, T, wa.Sc,
+                       wa.Gc * wa.KH * wa.KW, dw, db, wa.bias_from_S ? wa.Sc : wa.Gc);
+    VAE_LAUNCH_CHECK("wgrad_finalize_k");
+    return VAE_OK;
 }
 
 static int conv_igemm_fits(const vae_op& op, int B) {
@@ -401,6 +448,19 @@ static int conv_igemm_fits(const vae_op& op, int B) {
     const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     return plan_gather(f, B).SB >= 1 && plan_gather(d, B).SB >= 1 && w.SB >= 1 && g.sh <= 2 && g.sw <= 2;
+}
+
+extern "C" int64_t vae_conv_scratch_floats(const vae_op* op, int B) {
+    if (op == nullptr || (op->kind != VAE_OP_CONV && op->kind != VAE_OP_CONVT) || B < 1) return 0;
+    if (check_geom(*op) != VAE_OK) return 0;
+    const ConvGeom g = geom_of(*op);
+    const int T = op->kind == VAE_OP_CONVT;
+    const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
+                       : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+    if (w.SB < 1) return 0;
+    const int64_t slab = (int64_t)4 * (g.Cin > g.Cout ? g.Cin : g.Cout) * B;  // BatchNorm slabs: <= one row per sample
+    const int64_t part = wgrad_part_floats(w, B);
+    return slab > part ? slab : part;
 }
 
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B) {
@@ -417,15 +477,16 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     int wsum, tsum;
     a.ncls = fill_classes(a.g, a.cls, &wsum, &tsum);
     a.nchunks = (c.B + p.SB - 1) / p.SB;
+    a.dbgp = tune("VAE_DBGP", 0);
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
-    { const char* e = getenv("VAE_DBG_SKIPG"); a.dbg = e ? atoi(e) : 0; }
-    const int grid = a.nchunks < IG_MAX_GRID ? a.nchunks : IG_MAX_GRID;
+    const int g_max = IG_MAX_GRID;
+    const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
     if (a.g.Np > 16)
-        hipLaunchKernelGGL(igemm_gather_k<2>, dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        hipLaunchKernelGGL((igemm_gather_k<2, 2>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
     else
-        hipLaunchKernelGGL(igemm_gather_k<1>, dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        hipLaunchKernelGGL((igemm_gather_k<1, 2>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
     VAE_LAUNCH_CHECK(what);
     if (a.slab != nullptr) c.last_blocks = a.nchunks;
     return VAE_OK;
@@ -519,18 +580,20 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
         wa.Sc = g.Cin; wa.SH = g.H; wa.SW = g.W; wa.Gc = g.Cout; wa.GH = g.OH; wa.GW = g.OW;
     }
     if (wp.SB < 1) VAE_FAIL(VAE_EINVAL, "conv wgrad: layer does not fit the fused kernel");
-    wa.dw = dw; wa.dbias = db; wa.B = c.B; wa.SB = wp.SB;
+    wa.part = resolve(c, op.r[6], wgrad_part_floats(wp, c.B), "conv.wgrad_partials", &ok);
+    if (!ok) return VAE_EINVAL;
+    wa.dbgp = tune("VAE_DBGP", 0);
+    wa.want_bias = db != nullptr; wa.B = c.B; wa.SB = wp.SB;
     wa.KH = g.KH; wa.KW = g.KW; wa.sh = g.sh; wa.sw = g.sw; wa.ph = g.ph; wa.pw = g.pw;
-    wa.Hp = wp.Hp; wa.Wp = wp.Wp; wa.Mp = wp.Mp; wa.NKp = wp.NKp;
+    wa.Hp = wp.Hp; wa.Wp = wp.Wp;
     wa.dS_HW = mk_fdiv(wa.SH * wa.SW); wa.dS_W = mk_fdiv(wa.SW); wa.dS_CHW = mk_fdiv(wa.Sc * wa.SH * wa.SW);
     wa.dG_HW = mk_fdiv(wa.GH * wa.GW); wa.dG_W = mk_fdiv(wa.GW); wa.dG_CHW = mk_fdiv(wa.Gc * wa.GH * wa.GW);
     wa.d_KK = mk_fdiv(g.KH * g.KW); wa.d_KW = mk_fdiv(g.KW);
+    wa.d_bC = mk_fdiv(wa.bias_from_S ? wa.Sc : wa.Gc);
     wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
     wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
-    { const char* e = getenv("VAE_DBG_SKIP"); wa.dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(igemm_wgrad_k, dim3(wa.nchunks < IG_WG_MAX_GRID ? wa.nchunks : IG_WG_MAX_GRID), dim3(IG_THREADS),
-                       (size_t)wp.total * sizeof(float), c.s, wa);
-    VAE_LAUNCH_CHECK("igemm_wgrad_k");
+    rc = launch_wgrad(c, wa, wp, dw, db);
+    if (rc) return rc;
 
     // 2) input gradient
     if (dx == nullptr) return VAE_OK;

@@ -175,7 +175,7 @@ class ProgramBuilder:
         for op in self.ops:
             if op.kind in convs and lib.vae_conv_fused_ok(ctypes.byref(op), self.B):
                 op.flags |= L.F_FUSED
-                self.scratch_need = max(self.scratch_need, 4 * max(op.d[0], op.d[3]) * self.B)
+                self.scratch_need = max(self.scratch_need, lib.vae_conv_scratch_floats(ctypes.byref(op), self.B))
         out_refs = {buf.ref for buf, _ in self.outputs.values()}
         for bn in self.ops:
             if bn.kind != L.OP_BN or bn.r[1] in out_refs:
