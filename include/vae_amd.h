@@ -104,7 +104,7 @@ typedef struct vae_op {
 } vae_op;
 
 #define VAE_MAX_CHUNKS 64
-#define VAE_ELBO_BLOCKS 256
+#define VAE_ELBO_BLOCKS 1024
 
 const char* vae_last_error(void);
 /* Queries device 0..: returns 0 if the current device is gfx950, VAE_ENODEV otherwise. */

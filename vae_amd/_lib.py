@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvae_amd.so")
 OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
-MAX_CHUNKS, ELBO_BLOCKS = 64, 256
+MAX_CHUNKS, ELBO_BLOCKS = 64, 1024
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
 
 

@@ -64,12 +64,29 @@ __global__ __launch_bounds__(256) void elbo_fwd_k(const float* __restrict__ xr, 
     float rec = 0.f, kl = 0.f;
     const int64_t nrec = B * nps, nkl = B * latent;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
-        const int64_t b = i / nps;
-        const int j = (int)(i - b * nps);
-        const float p = xr[i], t = tg[b * t_sb + j * t_se];
-        if (bce) rec += bce_term(p, t);
-        else rec = fmaf(p - t, p - t, rec);
+    if (t_se == 1 && t_sb == nps) {  // target laid out like x_rec: no index arithmetic (a 64-bit divide per
+                                     // element costs more than the two logs)
+        float rec2 = 0.f;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < nrec; i += 2 * stride) {
+            const float p0 = xr[i], t0 = tg[i], p1 = xr[i + stride], t1 = tg[i + stride];
+            if (bce) { rec += bce_term(p0, t0); rec2 += bce_term(p1, t1); }
+            else { rec = fmaf(p0 - t0, p0 - t0, rec); rec2 = fmaf(p1 - t1, p1 - t1, rec2); }
+        }
+        if (i < nrec) {
+            const float p = xr[i], t = tg[i];
+            if (bce) rec += bce_term(p, t);
+            else rec = fmaf(p - t, p - t, rec);
+        }
+        rec += rec2;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
+            const int64_t b = i / nps;
+            const int j = (int)(i - b * nps);
+            const float p = xr[i], t = tg[b * t_sb + j * t_se];
+            if (bce) rec += bce_term(p, t);
+            else rec = fmaf(p - t, p - t, rec);
+        }
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nkl; i += stride) {
         const float m = mu[i], l = lv[i];
@@ -111,9 +128,12 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
     const int64_t nrec = B * nps, nkl = B * latent;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
-        const int64_t b = i / nps;
-        const int j = (int)(i - b * nps);
-        const float p = xr[i], t = tg[b * t_sb + j * t_se];
+        int64_t ti = i;
+        if (!(t_se == 1 && t_sb == nps)) {
+            const int64_t b = i / nps;
+            ti = b * t_sb + (i - b * nps) * t_se;
+        }
+        const float p = xr[i], t = tg[ti];
         float g;
         if (bce) g = (p - t) / fmaxf((1.f - p) * p, 1e-12f);  // torch's binary_cross_entropy_backward
         else g = 2.f * (p - t);

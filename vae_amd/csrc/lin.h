@@ -33,9 +33,12 @@ struct LinArgs {
     int Kp;           // KC + 1: odd row stride of the A tile
     int a_act, act, accumulate;
     float a_slope, slope;
-    FastDiv d_KC;
+    FastDiv d_KC, d_KC4;  // by KC and by KC/4
 };
 
+// VEC: rows are 16-byte aligned and K, N are multiples of 4 where it matters (host-checked), so the tile
+// is fetched with dwordx4 loads: a quarter of the load instructions, all of a pass in flight at once.
+template <bool VEC>
 __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [32][Kp]
@@ -52,6 +55,52 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
     const bool nfast = (a.wsn == 1);
     for (int kc0 = 0; kc0 < a.K; kc0 += a.KC) {
         if (kc0 > 0) __syncthreads();
+        if (VEC) {
+            const int total4 = total >> 2;  // groups of 4 consecutive k (A, W[n][k]) or n (W[k][n])
+            constexpr int U = 5;
+            for (int base = tid; base < total4; base += LIN_THREADS * U) {
+                float4 va[U], vy[U], vw[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int e = base + j * LIN_THREADS;
+                    va[j] = vw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    vy[j] = va[j];
+                    if (e < total4) {
+                        const int r = fdiv((uint32_t)e, a.d_KC4), k = (e - r * (a.KC >> 2)) << 2;
+                        if (m0 + r < a.B && kc0 + k < a.K) {
+                            va[j] = *reinterpret_cast<const float4*>(a.A + (int64_t)(m0 + r) * a.lda + kc0 + k);
+                            if (a.A2 != nullptr)
+                                vy[j] = *reinterpret_cast<const float4*>(a.A2 + (int64_t)(m0 + r) * a.lda2 + kc0 + k);
+                        }
+                        const int wn = nfast ? (e & 7) << 2 : r, wk = nfast ? (e >> 3) : k;
+                        if (n0 + wn < a.N && kc0 + wk < a.K)
+                            vw[j] = *reinterpret_cast<const float4*>(a.W + (int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int e = base + j * LIN_THREADS;
+                    if (e < total4) {
+                        const int r = fdiv((uint32_t)e, a.d_KC4), k = (e - r * (a.KC >> 2)) << 2;
+                        if (a.A2 != nullptr) {
+                            va[j].x *= act_grad_from_out(vy[j].x, a.a_act, a.a_slope);
+                            va[j].y *= act_grad_from_out(vy[j].y, a.a_act, a.a_slope);
+                            va[j].z *= act_grad_from_out(vy[j].z, a.a_act, a.a_slope);
+                            va[j].w *= act_grad_from_out(vy[j].w, a.a_act, a.a_slope);
+                        }
+                        float* ad = As + r * a.Kp + k;
+                        ad[0] = va[j].x; ad[1] = va[j].y; ad[2] = va[j].z; ad[3] = va[j].w;
+                        if (nfast) {
+                            float* wd = Ws + (e >> 3) * LIN_WS + ((e & 7) << 2);
+                            wd[0] = vw[j].x; wd[1] = vw[j].y; wd[2] = vw[j].z; wd[3] = vw[j].w;
+                        } else {
+                            float* wd = Ws + k * LIN_WS + r;
+                            wd[0] = vw[j].x; wd[LIN_WS] = vw[j].y; wd[2 * LIN_WS] = vw[j].z; wd[3 * LIN_WS] = vw[j].w;
+                        }
+                    }
+                }
+            }
+        } else
         for (int base = tid; base < total; base += LIN_THREADS * 8) {
             float va[8], vw[8];
 #pragma unroll

@@ -721,9 +721,17 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     a.KC = ((K16 + passes - 1) / passes + 15) / 16 * 16;
     a.Kp = a.KC + 1;
     a.d_KC = mk_fdiv((uint32_t)a.KC);
+    a.d_KC4 = mk_fdiv((uint32_t)(a.KC / 4));
+    // dwordx4 staging needs every row start 16-byte aligned and whole groups of 4 inside the edges
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    bool vec = a.K % 4 == 0 && a.lda % 4 == 0 && al16(a.A) && al16(a.W);
+    if (a.A2 != nullptr) vec = vec && a.lda2 % 4 == 0 && al16(a.A2);
+    if (a.wsn == 1) vec = vec && a.wsk % 4 == 0 && a.N % 4 == 0;  // W'[k][n], n contiguous
+    else vec = vec && a.wsn % 4 == 0 && a.wsk == 1;               // W'[n][k], k contiguous
     const size_t bytes = (size_t)(LIN_BM * a.Kp + a.KC * LIN_WS) * sizeof(float);
     dim3 grid((a.B + LIN_BM - 1) / LIN_BM, (a.N + LIN_BN - 1) / LIN_BN);
-    hipLaunchKernelGGL(lin_fwd_k, grid, dim3(LIN_THREADS), bytes, c.s, a);
+    if (vec) hipLaunchKernelGGL(lin_fwd_k<true>, grid, dim3(LIN_THREADS), bytes, c.s, a);
+    else hipLaunchKernelGGL(lin_fwd_k<false>, grid, dim3(LIN_THREADS), bytes, c.s, a);
     VAE_LAUNCH_CHECK(what);
     return VAE_OK;
 }
