@@ -34,20 +34,24 @@ struct TensorIn {
     float slope;
 };
 
-// `coef` is the LDS copy of t.coef (8*C floats) made once per workgroup.
-__device__ __forceinline__ float tensor_in_value(const TensorIn& t, const float* coef, int64_t e, int c, int C) {
-    float v = t.src[e];
+// `coef` is the LDS copy of t.coef (8*C floats) made once per workgroup.  v = src[e], y = src2[e]
+// (y is only read by the gradient modes).
+__device__ __forceinline__ float tensor_transform(const TensorIn& t, const float* coef, float v, float y, int c, int C) {
     if (t.mode == TR_BN) {
         v = fmaf(v - coef[c], coef[2 * C + c], coef[3 * C + c]);  // (y - mean) * scale + beta
         if (t.relu) v = v > 0.f ? v : 0.f;
     } else if (t.mode == TR_GRAD_BN) {
-        const float y = t.src2[e];
         v = fmaf(coef[4 * C + c], v, fmaf(coef[5 * C + c], y - coef[c], coef[6 * C + c]));
         v *= act_grad_from_out(y, t.act, t.slope);
     } else if (t.mode == TR_GRAD_ACT) {
-        v *= act_grad_from_out(t.src2[e], t.act, t.slope);
+        v *= act_grad_from_out(y, t.act, t.slope);
     }
     return v;
+}
+__device__ __forceinline__ float tensor_in_value(const TensorIn& t, const float* coef, int64_t e, int c, int C) {
+    const float v = t.src[e];
+    const float y = t.mode >= TR_GRAD_BN ? t.src2[e] : 0.f;
+    return tensor_transform(t, coef, v, y, c, C);
 }
 
 struct FastDiv {  // exact n / d for n * d < 2^32
@@ -95,7 +99,7 @@ struct IgArgs {
     // LDS carve (floats)
     int lds_in, lds_w, lds_out, lds_tab;
     int ncls, nchunks;
-    int dbgp;
+    int pre;  // 1: chunks fit the register prefetch (<= IG_PRE*IG_THREADS input elements)
     FastDiv d_N, d_ntile;  // by N and by Np/16
     IgClass cls[4];
 };
@@ -103,6 +107,8 @@ struct IgArgs {
 #define IG_THREADS 512
 #define IG_WAVES (IG_THREADS / 64)
 #define IG_UNROLL 8
+#define IG_PRE 16     // gather: prefetch registers per lane
+#define WG_PRE 8      // wgrad: per tensor
 
 // Stage [sb][C][H][W] (global, contiguous) into the padded LDS image, applying the transform.
 // IG_UNROLL independent elements per lane and iteration: all their global loads are in flight
@@ -136,13 +142,77 @@ __device__ __forceinline__ void ig_stage(const TensorIn& t, const float* coef, f
     }
 }
 
+// Register prefetch of the NEXT chunk: pre_load only issues the global loads (nothing waits on them until
+// pre_store, one chunk of compute later); pre_store transforms and writes the padded LDS image.  Where
+// element (lane, j) lands does not depend on the chunk, so it is decoded once per workgroup into
+// meta[j] = lds offset | channel << 16.  A tensor chunk holds <= PRE * IG_THREADS elements (host-checked).
+// HASY: the tensor is read in a gradient mode (needs src2).
+template <int PRE, bool HASY>
+struct PreRegs {
+    float v[PRE], y[HASY ? PRE : 1];
+    uint32_t meta[PRE];
+};
+// keeps the compiler from hoisting per-slot address arithmetic out of the chunk loop into registers
+__device__ __forceinline__ uint32_t opaque_tid() {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+template <int PRE, bool HASY>
+__device__ __forceinline__ void pre_decode(PreRegs<PRE, HASY>& p, uint32_t total, int C, int HW, int W, int Hp, int Wp,
+                                           int halo_h, int halo_w, FastDiv d_CHW, FastDiv d_HW, FastDiv d_W) {
+    const int chw_p = C * Hp * Wp;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) {
+        const uint32_t e = threadIdx.x + j * IG_THREADS;
+        p.meta[j] = 0;
+        if (e < total) {
+            const uint32_t s = fdiv(e, d_CHW);
+            const uint32_t r = e - s * (uint32_t)(C * HW);
+            const uint32_t c = fdiv(r, d_HW);
+            const uint32_t pos = r - c * (uint32_t)HW;
+            const uint32_t ih = fdiv(pos, d_W);
+            const uint32_t iw = pos - ih * (uint32_t)W;
+            p.meta[j] = (s * chw_p + c * Hp * Wp + (ih + halo_h) * Wp + iw + halo_w) | (c << 16);
+        }
+    }
+}
+template <int PRE, bool HASY>
+__device__ __forceinline__ void pre_load(const TensorIn& t, int64_t gbase, uint32_t total, PreRegs<PRE, HASY>& p) {
+    const uint32_t t0 = opaque_tid();
+    const float* src = t.src + gbase;
+    const float* src2 = t.src2 != nullptr ? t.src2 + gbase : nullptr;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) {
+        const uint32_t e = t0 + j * IG_THREADS;
+        if (e < total) {
+            p.v[j] = src[e];
+            if (HASY && t.mode >= TR_GRAD_BN) p.y[j] = src2[e];  // (src2 is null in the plain modes)
+        }
+    }
+}
+template <int PRE, bool HASY>
+__device__ __forceinline__ void pre_store(const TensorIn& t, const float* coef, float* lds, uint32_t total, int C,
+                                          const PreRegs<PRE, HASY>& p) {
+    const uint32_t t0 = opaque_tid();
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) {
+        const uint32_t e = t0 + j * IG_THREADS;
+        // (meta is chunk-invariant: hidden from the optimiser, else it hoists every slot's coefficient
+        // addresses out of the chunk loop into ~100 registers and halves the occupancy)
+        uint32_t m = p.meta[j];
+        asm volatile("" : "+v"(m));
+        if (e < total) lds[m & 0xffffu] = tensor_transform(t, coef, p.v[j], HASY ? p.y[j] : 0.f, (int)(m >> 16), C);
+    }
+}
+
 __device__ __forceinline__ void ig_load_coef(const float* g, float* l, int n) {
     if (g != nullptr)
         for (int i = threadIdx.x; i < n; i += IG_THREADS) l[i] = g[i];
 }
 
-template <int NT, int TI>
-__global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
+template <int NT, int TI, bool GRAD>
+__global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_gather_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
     float* lin = smem;
@@ -159,7 +229,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
     const int OHW = g.OH * g.OW;
     const int n_ntile = g.Np >> 4;
 
-    long long T0 = wall_clock64(), Tst = 0, Tti = 0, Tco = 0, Tsetup, t1, t2;
     // ---- once per workgroup: clear the input image (the halo must read as zero and is never
     // written again), build the tap-offset tables and the [k][n] weight images of every class
     for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
@@ -191,16 +260,30 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
         }
     }
 
-    Tsetup = wall_clock64() - T0;
+    const int CHW = g.Cin * g.H * g.W;
+    PreRegs<IG_PRE, GRAD> pr;
+    if (a.pre) {
+        pre_decode(pr, (uint32_t)(a.SB * CHW), g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w, g.d_CHW, g.d_HW,
+                   g.d_W);
+        if ((int)blockIdx.x < a.nchunks)
+            pre_load(a.in, (int64_t)blockIdx.x * a.SB * CHW, (uint32_t)(min(a.SB, a.B - (int)blockIdx.x * a.SB) * CHW),
+                     pr);
+    }
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
-        t1 = wall_clock64();
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
         __syncthreads();  // previous chunk's copy-out is done with lout; tables/coefficients are ready
-        ig_stage(a.in, cin, lin, (int64_t)s0 * g.Cin * g.H * g.W, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h,
-                 g.halo_w, g.d_CHW, g.d_HW, g.d_W);
+        if (a.pre)
+            pre_store(a.in, cin, lin, (uint32_t)(sb * CHW), g.Cin, pr);
+        else
+            ig_stage(a.in, cin, lin, (int64_t)s0 * CHW, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
+                     g.d_CHW, g.d_HW, g.d_W);
         __syncthreads();
-        t2 = wall_clock64(); Tst += t2 - t1; t1 = t2;
+        {  // the next chunk's loads fly while this one is computed
+            const int nx = chunk + gridDim.x;
+            if (a.pre && nx < a.nchunks)
+                pre_load(a.in, (int64_t)nx * a.SB * CHW, (uint32_t)(min(a.SB, a.B - nx * a.SB) * CHW), pr);
+        }
 
         // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
         int tile_base = 0;
@@ -276,7 +359,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
             tile_base += ntile;
         }
         __syncthreads();
-        t2 = wall_clock64(); Tti += t2 - t1; t1 = t2;
 
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
         const int64_t obase = (int64_t)s0 * g.N * OHW;
@@ -285,7 +367,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
             // (the activation runs here, once per real output element with every lane busy, not in the
             // MFMA epilogue where 15 of 16 lanes may hold padding channels)
             for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
-            t2 = wall_clock64(); Tco += t2 - t1;
             continue;
         }
         // one wave per channel: it walks that channel's row in every sample of the chunk, so the two
@@ -334,10 +415,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_gather_k(IgArgs a) {
                 }
             }
         }
-        t2 = wall_clock64(); Tco += t2 - t1;
     }
-    if (a.dbgp && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-        printf("gather<%d,%d> blk %d: setup %lld stage %lld tiles %lld copyout %lld total %lld (x10ns) SB %d nchunks %d grid %d ep %d slab %d\n", NT, TI, blockIdx.x, Tsetup, Tst, Tti, Tco, wall_clock64() - T0, a.SB, a.nchunks, gridDim.x, a.ep_mode, a.slab != nullptr);
 }
 
 // ---- weight gradient --------------------------------------------------------------------------
@@ -354,7 +432,7 @@ struct WgArgs {
     TensorIn S, G;
     float* part;      // [gridDim.x][MT*NT*256 + 64] workgroup partials (reduced by wgrad_finalize_k)
     int want_bias;
-    int dbgp;
+    int pre;  // 1: chunks fit the register prefetch (<= WG_PRE*IG_THREADS elements of S and of G)
     int bias_from_S;  // 1: dbias from S (Conv), 0: from G (ConvT)
     int B, SB, nchunks;
     int Sc, SH, SW;   // S: channels, small grid
@@ -369,7 +447,7 @@ struct WgArgs {
 // is issued before its first MFMA and the loop has no branches.  Rows m >= Sc and columns
 // n >= Gc*KH*KW read a clamped (valid) row/column; their results are simply never written.
 template <int MT, int NT>
-__global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
+__global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 5 ? 4 : 2, MT * NT <= 5 ? 4 : 2))) void igemm_wgrad_k(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lS = smem;                 // [sb][Sc][SHW]
     float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]
@@ -384,7 +462,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
     const int NK = a.Gc * KK;
     const int Pfull = a.SB * SHW;
 
-    long long T0 = wall_clock64(), Tst = 0, Tbi = 0, Tmf = 0, Tsetup, Tloop, t1, t2;
     for (int i = tid; i < a.lds_G; i += IG_THREADS) lG[i] = 0.f;  // halo stays zero for every chunk
     ig_load_coef(a.S.coef, cS, 8 * a.Sc);
     ig_load_coef(a.G.coef, cG, 8 * a.Gc);
@@ -412,19 +489,41 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
     }
     float bsum = 0.f;  // lane c of every wave: this wave's share of the bias gradient of channel c (< 64)
 
-    Tsetup = wall_clock64() - T0;
+    const int SCHW = a.Sc * SHW, GCHW = a.Gc * a.GH * a.GW;
+    PreRegs<WG_PRE, true> pS, pG;
+    if (a.pre) {
+        pre_decode(pS, (uint32_t)(a.SB * SCHW), a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W);
+        pre_decode(pG, (uint32_t)(a.SB * GCHW), a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw, a.dG_CHW, a.dG_HW,
+                   a.dG_W);
+    }
+    if (a.pre && (int)blockIdx.x < a.nchunks) {
+        const int nsb = min(a.SB, a.B - (int)blockIdx.x * a.SB);
+        pre_load(a.S, (int64_t)blockIdx.x * a.SB * SCHW, (uint32_t)(nsb * SCHW), pS);
+        pre_load(a.G, (int64_t)blockIdx.x * a.SB * GCHW, (uint32_t)(nsb * GCHW), pG);
+    }
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
-        t1 = wall_clock64();
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
         const int P = sb * SHW;
         __syncthreads();  // tables ready / previous chunk's MFMAs are done with the tiles
-        ig_stage(a.S, cS, lS, (int64_t)s0 * a.Sc * SHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW,
-                 a.dS_W);
-        ig_stage(a.G, cG, lG, (int64_t)s0 * a.Gc * a.GH * a.GW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw,
-                 a.dG_CHW, a.dG_HW, a.dG_W);
+        if (a.pre) {
+            pre_store(a.S, cS, lS, (uint32_t)(sb * SCHW), a.Sc, pS);
+            pre_store(a.G, cG, lG, (uint32_t)(sb * GCHW), a.Gc, pG);
+        } else {
+            ig_stage(a.S, cS, lS, (int64_t)s0 * SCHW, sb, a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW,
+                     a.dS_W);
+            ig_stage(a.G, cG, lG, (int64_t)s0 * GCHW, sb, a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw, a.dG_CHW,
+                     a.dG_HW, a.dG_W);
+        }
         __syncthreads();
-        t2 = wall_clock64(); Tst += t2 - t1; t1 = t2;
+        {  // the next chunk's loads fly while this one is computed
+            const int nx = chunk + gridDim.x;
+            if (a.pre && nx < a.nchunks) {
+                const int nsb = min(a.SB, a.B - nx * a.SB);
+                pre_load(a.S, (int64_t)nx * a.SB * SCHW, (uint32_t)(nsb * SCHW), pS);
+                pre_load(a.G, (int64_t)nx * a.SB * GCHW, (uint32_t)(nsb * GCHW), pG);
+            }
+        }
         // bias gradient = per-channel sum of the d(pre-activation) image (its zero halo adds nothing):
         // the (sample, channel) rows go round-robin over the waves
         if (a.want_bias) {
@@ -440,7 +539,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
                 if (lane == c) bsum += t;
             }
         }
-        t2 = wall_clock64(); Tbi += t2 - t1; t1 = t2;
         // pixels: four per MFMA step, two independent steps per iteration, steps round-robin over the waves
         for (int q4 = wid * 4; q4 < P; q4 += 8 * IG_WAVES) {
             const int qa = q4 + lk, qb = qa + 4 * IG_WAVES;
@@ -470,10 +568,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
                     for (int mt = 0; mt < MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][mt], bv[h][nt], acc[mt][nt], 0, 0, 0);
         }
-        t2 = wall_clock64(); Tmf += t2 - t1;
     }
     __syncthreads();
-    Tloop = wall_clock64() - T0;
     // cross-wave reduction in LDS (rbuf overlays the dead S/G tiles; the host sizes them >= MT*NT*256);
     // the workgroup's partial goes to its own row of `part` in accumulator-tile order, bias sums behind it
     // (global atomics on the few cache lines of dw serialise in L2 and cost more than the whole MFMA loop)
@@ -516,8 +612,6 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_k(WgArgs a) {
         for (int w = 0; w < IG_WAVES; ++w) t += bred[w * 64 + tid];
         row[MT * NT * 256 + tid] = t;
     }
-    if (a.dbgp && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-        printf("wgrad<%d,%d> blk %d: setup %lld stage %lld bias %lld mfma %lld loop_end %lld total %lld (x10ns) SB %d nchunks %d\n", MT, NT, blockIdx.x, Tsetup, Tst, Tbi, Tmf, Tloop, wall_clock64() - T0, a.SB, a.nchunks);
 }
 
 // Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias.  One workgroup per 32

@@ -242,7 +242,7 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 static int tune(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 #define IG_LDS_BUDGET_FLOATS tune("VAE_T_LDS", 16000)  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
 #define IG_WG_LDS_BUDGET tune("VAE_T_WGLDS", 16000)
-#define IG_WG_MAX_GRID tune("VAE_T_WGGRID", 256)          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
+#define IG_WG_MAX_GRID tune("VAE_T_WGGRID", 512)          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
                                     // workgroups also keep the global atomics on dw/dbias rare
 #define IG_MAX_GRID tune("VAE_T_GRID", 512)            // persistent workgroups (up to 4 per CU), each loops over its chunks
 #define IG_SB_TARGET tune("VAE_T_SBT", 1024)
@@ -302,7 +302,7 @@ static IgGeom make_geom(int transposed, int Cin, int H, int W, int N, int OH, in
 }
 
 struct IgPlan {
-    int SB, lds_in, lds_w, lds_out, lds_tab, total;
+    int SB, lds_in, lds_w, lds_out, lds_tab, total, pre;
 };
 // Host mirror of the per-class tap enumeration (igemm.h IgClass); returns the class count.
 static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
@@ -338,6 +338,7 @@ static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
 // LDS need of the gather kernel for SB samples per chunk; picks SB for batch B (0 if it cannot fit)
 static IgPlan plan_gather(const IgGeom& g, int B) {
     IgPlan p;
+    memset(&p, 0, sizeof(p));
     IgClass cls[4];
     int wsum = 0, tsum = 0;
     if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
@@ -353,6 +354,10 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
         if (sb > fit) sb = fit;
         if (sb < 1) sb = 1;
         if (sb > B) sb = B;
+        // register prefetch of the next chunk needs the chunk's input in IG_PRE registers per lane
+        const int cap = IG_PRE * IG_THREADS / (g.Cin * g.H * g.W);
+        p.pre = cap >= 1;
+        if (p.pre && sb > cap) sb = cap;
     }
     p.SB = sb;
     p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * per_out; p.lds_tab = tsum;
@@ -364,7 +369,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
 }
 
 struct WgPlan {
-    int SB, lds_S, lds_G, lds_tab, total, Hp, Wp, MT, NT;
+    int SB, lds_S, lds_G, lds_tab, total, Hp, Wp, MT, NT, pre;
 };
 // accumulator-tile buckets igemm_wgrad_k is instantiated for (MT x NT tiles of 16x16 per wave)
 static int wgrad_bucket(int Sc, int NK, int* MT, int* NT) {
@@ -395,6 +400,11 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
         if (sb < 1) sb = 1;
         if (sb > B) sb = B;
         if (sb * (per_S + per_G) < T * 256 && (B >= fit)) sb = 0;
+        // register prefetch of the next chunk: WG_PRE registers per lane and tensor
+        const int big = per_S > Gc * GH * GW ? per_S : Gc * GH * GW;
+        const int cap = WG_PRE * IG_THREADS / big;
+        p.pre = cap >= 1 && sb >= 1;
+        if (p.pre && sb > cap) sb = cap;
     }
     p.SB = sb;
     p.lds_S = sb * per_S; p.lds_G = sb * per_G;
@@ -472,21 +482,24 @@ extern "C" int vae_conv_fused_ok(const vae_op* op, int B) {
 static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const IgPlan p = plan_gather(a.g, c.B);
     if (p.SB < 1) VAE_FAIL(VAE_EINVAL, "%s: layer does not fit the fused conv kernel's LDS budget", what);
-    a.B = c.B; a.SB = p.SB;
+    a.B = c.B; a.SB = p.SB; a.pre = p.pre;
     a.lds_in = p.lds_in; a.lds_w = p.lds_w; a.lds_out = p.lds_out; a.lds_tab = p.lds_tab;
     int wsum, tsum;
     a.ncls = fill_classes(a.g, a.cls, &wsum, &tsum);
     a.nchunks = (c.B + p.SB - 1) / p.SB;
-    a.dbgp = tune("VAE_DBGP", 0);
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
     const int g_max = IG_MAX_GRID;
     const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
-    if (a.g.Np > 16)
-        hipLaunchKernelGGL((igemm_gather_k<2, 2>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
-    else
-        hipLaunchKernelGGL((igemm_gather_k<1, 2>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+    const bool grad = a.in.mode >= TR_GRAD_BN;
+    if (a.g.Np > 16) {
+        if (grad) hipLaunchKernelGGL((igemm_gather_k<2, 2, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        else hipLaunchKernelGGL((igemm_gather_k<2, 2, false>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+    } else {
+        if (grad) hipLaunchKernelGGL((igemm_gather_k<1, 2, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        else hipLaunchKernelGGL((igemm_gather_k<1, 2, false>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+    }
     VAE_LAUNCH_CHECK(what);
     if (a.slab != nullptr) c.last_blocks = a.nchunks;
     return VAE_OK;
@@ -582,7 +595,7 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     if (wp.SB < 1) VAE_FAIL(VAE_EINVAL, "conv wgrad: layer does not fit the fused kernel");
     wa.part = resolve(c, op.r[6], wgrad_part_floats(wp, c.B), "conv.wgrad_partials", &ok);
     if (!ok) return VAE_EINVAL;
-    wa.dbgp = tune("VAE_DBGP", 0);
+    wa.pre = wp.pre;
     wa.want_bias = db != nullptr; wa.B = c.B; wa.SB = wp.SB;
     wa.KH = g.KH; wa.KW = g.KW; wa.sh = g.sh; wa.sw = g.sw; wa.ph = g.ph; wa.pw = g.pw;
     wa.Hp = wp.Hp; wa.Wp = wp.Wp;
