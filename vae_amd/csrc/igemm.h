@@ -229,37 +229,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int OHW = g.OH * g.OW;
     const int n_ntile = g.Np >> 4;
 
-    // ---- once per workgroup: clear the input image (the halo must read as zero and is never
-    // written again), build the tap-offset tables and the [k][n] weight images of every class
-    for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
-    ig_load_coef(a.in.coef, cin, 8 * g.Cin);
-    ig_load_coef(a.ep_coef, cep, 8 * g.N);
-    for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
-    for (int cls = 0; cls < a.ncls; ++cls) {
-        const IgClass& c = a.cls[cls];
-        const int nw = c.KcPad * g.Np;
-        for (int i = tid; i < nw; i += IG_THREADS) {
-            const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
-            const int n = i - k * g.Np;
-            float v = 0.f;
-            int off = 0;  // k >= Kc: the weight row is zero, any finite in-range operand will do
-            if (k < c.Kc) {
-                const int ci = fdiv((uint32_t)k, c.d_ntaps), ti = k - ci * c.ntaps;
-                const int i_h = fdiv((uint32_t)ti, c.d_nkw), i_w = ti - i_h * c.nkw;
-                const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
-                int ro = kh, co = kw;
-                if (g.transposed) {
-                    ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
-                    co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
-                }
-                off = ci * HpWp + ro * g.Wp + co;
-                if (n < g.N) v = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
-            }
-            lw[c.woff + i] = v;
-            if (n == 0) ktab[c.toff + k] = off;
-        }
-    }
-
+    // the first chunk's loads are issued before anything else: the set-up below hides their latency
     const int CHW = g.Cin * g.H * g.W;
     PreRegs<IG_PRE, GRAD> pr;
     if (a.pre) {
@@ -269,6 +239,50 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             pre_load(a.in, (int64_t)blockIdx.x * a.SB * CHW, (uint32_t)(min(a.SB, a.B - (int)blockIdx.x * a.SB) * CHW),
                      pr);
     }
+    // ---- once per workgroup: clear the input image (the halo must read as zero and is never
+    // written again), build the tap-offset tables and the [k][n] weight images of every class
+    for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
+    ig_load_coef(a.in.coef, cin, 8 * g.Cin);
+    ig_load_coef(a.ep_coef, cep, 8 * g.N);
+    for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
+    for (int cls = 0; cls < a.ncls; ++cls) {
+        const IgClass& c = a.cls[cls];
+        const int nw = c.KcPad * g.Np;
+        for (int base = tid; base < nw; base += IG_THREADS * 4) {  // four independent weight loads in flight
+            float v[4];
+            int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * IG_THREADS;
+                const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
+                const int n = i - k * g.Np;
+                v[u] = 0.f;
+                off[u] = 0;  // k >= Kc: the weight row is zero, any finite in-range operand will do
+                if (i < nw && k < c.Kc) {
+                    const int ci = fdiv((uint32_t)k, c.d_ntaps), ti = k - ci * c.ntaps;
+                    const int i_h = fdiv((uint32_t)ti, c.d_nkw), i_w = ti - i_h * c.nkw;
+                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
+                    int ro = kh, co = kw;
+                    if (g.transposed) {
+                        ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
+                        co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
+                    }
+                    off[u] = ci * HpWp + ro * g.Wp + co;
+                    if (n < g.N) v[u] = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * IG_THREADS;
+                if (i < nw) {
+                    lw[c.woff + i] = v[u];
+                    const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
+                    if (i == k * g.Np) ktab[c.toff + k] = off[u];
+                }
+            }
+        }
+    }
+
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
@@ -462,6 +476,19 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
     const int NK = a.Gc * KK;
     const int Pfull = a.SB * SHW;
 
+    // the first chunk's loads are issued before anything else: the set-up below hides their latency
+    const int SCHW = a.Sc * SHW, GCHW = a.Gc * a.GH * a.GW;
+    PreRegs<WG_PRE, true> pS, pG;
+    if (a.pre) {
+        pre_decode(pS, (uint32_t)(a.SB * SCHW), a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W);
+        pre_decode(pG, (uint32_t)(a.SB * GCHW), a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw, a.dG_CHW, a.dG_HW,
+                   a.dG_W);
+    }
+    if (a.pre && (int)blockIdx.x < a.nchunks) {
+        const int nsb = min(a.SB, a.B - (int)blockIdx.x * a.SB);
+        pre_load(a.S, (int64_t)blockIdx.x * a.SB * SCHW, (uint32_t)(nsb * SCHW), pS);
+        pre_load(a.G, (int64_t)blockIdx.x * a.SB * GCHW, (uint32_t)(nsb * GCHW), pG);
+    }
     for (int i = tid; i < a.lds_G; i += IG_THREADS) lG[i] = 0.f;  // halo stays zero for every chunk
     ig_load_coef(a.S.coef, cS, 8 * a.Sc);
     ig_load_coef(a.G.coef, cG, 8 * a.Gc);
@@ -489,18 +516,6 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
     }
     float bsum = 0.f;  // lane c of every wave: this wave's share of the bias gradient of channel c (< 64)
 
-    const int SCHW = a.Sc * SHW, GCHW = a.Gc * a.GH * a.GW;
-    PreRegs<WG_PRE, true> pS, pG;
-    if (a.pre) {
-        pre_decode(pS, (uint32_t)(a.SB * SCHW), a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W);
-        pre_decode(pG, (uint32_t)(a.SB * GCHW), a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw, a.dG_CHW, a.dG_HW,
-                   a.dG_W);
-    }
-    if (a.pre && (int)blockIdx.x < a.nchunks) {
-        const int nsb = min(a.SB, a.B - (int)blockIdx.x * a.SB);
-        pre_load(a.S, (int64_t)blockIdx.x * a.SB * SCHW, (uint32_t)(nsb * SCHW), pS);
-        pre_load(a.G, (int64_t)blockIdx.x * a.SB * GCHW, (uint32_t)(nsb * GCHW), pG);
-    }
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int s0 = chunk * a.SB;
         const int sb = min(a.SB, a.B - s0);
@@ -614,37 +629,36 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
     }
 }
 
-// Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias.  One workgroup per 32
-// partial columns; its 8 slices stride over the partial rows (128-byte coalesced reads).
+// Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias.  One workgroup per 16
+// partial columns; its 16 slices stride over the partial rows, eight independent loads in flight each.
 __global__ __launch_bounds__(256) void wgrad_finalize_k(const float* __restrict__ part, int nrows, int NT, int T,
                                                         int Sc, int NK, float* __restrict__ dw,
                                                         float* __restrict__ dbias, int C) {
-    __shared__ float red[8][32];
+    __shared__ float red[16][17];
     const int stride = T * 256 + 64;
-    const int jj = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + jj;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    const int jj = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + jj;
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = 0.f;
     int b = slice;
-    for (; b + 24 < nrows; b += 32) {
-        t0 += part[(int64_t)b * stride + j];
-        t1 += part[(int64_t)(b + 8) * stride + j];
-        t2 += part[(int64_t)(b + 16) * stride + j];
-        t3 += part[(int64_t)(b + 24) * stride + j];
-    }
-    for (; b < nrows; b += 8) t0 += part[(int64_t)b * stride + j];
-    red[slice][jj] = (t0 + t1) + (t2 + t3);
+    for (; b + 7 * 16 < nrows; b += 8 * 16)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] += part[(int64_t)(b + u * 16) * stride + j];
+    for (; b < nrows; b += 16) t[0] += part[(int64_t)b * stride + j];
+    red[slice][jj] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     __syncthreads();
     if (slice != 0) return;
-    float t = 0.f;
+    float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][jj];
+    for (int k = 0; k < 16; ++k) sum += red[k][jj];
     if (j < T * 256) {
         const int tile = j >> 8, r = (j >> 6) & 3, l = j & 63;
         const int mt = tile / NT, nt = tile - mt * NT;
         const int m = mt * 16 + (l >> 4) * 4 + r, n = nt * 16 + (l & 15);
-        if (m < Sc && n < NK) dw[(int64_t)m * NK + n] += t;
+        if (m < Sc && n < NK) dw[(int64_t)m * NK + n] += sum;
     } else if (dbias != nullptr && j - T * 256 < C) {
-        dbias[j - T * 256] += t;
+        dbias[j - T * 256] += sum;
     }
 }
 
@@ -663,21 +677,23 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
     }
     n = tot;
 }
-__global__ __launch_bounds__(64) void bnv_finalize_fwd_k(const float* __restrict__ slab, int nblocks,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ save,
-                                                         float* __restrict__ rmean, float* __restrict__ rvar, int C,
-                                                         float eps, float momentum, int training) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+#define BNV_THREADS 256
+__global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_fwd_k(const float* __restrict__ slab, int nblocks,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ save, float* __restrict__ rmean,
+                                                                  float* __restrict__ rvar, int C, float eps,
+                                                                  float momentum, int training) {
+    __shared__ float part[BNV_THREADS / 64][3];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float mean, var;
     if (training) {
         float n = 0.f, mu = 0.f, m2 = 0.f;
-        for (int k = lane; k < nblocks; k += 64) {
-            const float* sl = slab + ((int64_t)k * C + c) * 4;
-            const float nb = sl[3];
-            if (nb > 0.f) {
-                const float d = sl[1] / nb;
-                chan_merge(n, mu, m2, nb, sl[0] + d, fmaxf(sl[2] - sl[1] * d, 0.f));
+        for (int k = tid; k < nblocks; k += BNV_THREADS) {
+            const float4 sl = *reinterpret_cast<const float4*>(slab + ((int64_t)k * C + c) * 4);
+            if (sl.w > 0.f) {
+                const float d = sl.y / sl.w;
+                chan_merge(n, mu, m2, sl.w, sl.x + d, fmaxf(sl.z - sl.y * d, 0.f));
             }
         }
 #pragma unroll
@@ -692,47 +708,54 @@ __global__ __launch_bounds__(64) void bnv_finalize_fwd_k(const float* __restrict
                 chan_merge(n, mu, m2, nb, mb, m2b);
             }
         }
+        if (lane == 0) { part[wid][0] = n; part[wid][1] = mu; part[wid][2] = m2; }
+        __syncthreads();
+        if (tid != 0) return;
+#pragma unroll
+        for (int w = 1; w < BNV_THREADS / 64; ++w) chan_merge(n, mu, m2, part[w][0], part[w][1], part[w][2]);
         mean = mu;
         var = n > 0.f ? m2 / n : 0.f;
-        if (lane == 0) {
-            const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-        }
+        const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     } else {
+        if (tid != 0) return;
         mean = rmean[c];
         var = rvar[c];
     }
-    if (lane == 0) {
-        const float rstd = rsqrtf(var + eps);
-        save[c] = mean;
-        save[C + c] = rstd;
-        save[2 * C + c] = gamma[c] * rstd;
-        save[3 * C + c] = beta[c];
-    }
+    const float rstd = rsqrtf(var + eps);
+    save[c] = mean;
+    save[C + c] = rstd;
+    save[2 * C + c] = gamma[c] * rstd;
+    save[3 * C + c] = beta[c];
 }
 // backward: slab of {sum g, sum g*xhat} -> dgamma, dbeta and (a, b, c) of dy = a*g + b*(y-mean) + c
-__global__ __launch_bounds__(64) void bnv_finalize_bwd_k(const float* __restrict__ slab, int nblocks,
-                                                         float* __restrict__ save, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int C, int64_t n) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_bwd_k(const float* __restrict__ slab, int nblocks,
+                                                                  float* __restrict__ save, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int C, int64_t n) {
+    __shared__ float part[BNV_THREADS / 64][2];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = lane; k < nblocks; k += 64) {
-        s1 += slab[((int64_t)k * C + c) * 4];
-        s2 += slab[((int64_t)k * C + c) * 4 + 1];
+    for (int k = tid; k < nblocks; k += BNV_THREADS) {
+        const float2 sl = *reinterpret_cast<const float2*>(slab + ((int64_t)k * C + c) * 4);
+        s1 += sl.x;
+        s2 += sl.y;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         s1 += __shfl_xor(s1, off, 64);
         s2 += __shfl_xor(s2, off, 64);
     }
-    if (lane == 0) {
-        dbeta[c] = s1;
-        dgamma[c] = s2;
-        const float m1 = s1 / (float)n, m2 = s2 / (float)n;
-        const float rstd = save[C + c], sc = save[2 * C + c];
-        save[4 * C + c] = sc;  // dy = sc*(g - m1 - xhat*m2)
-        save[5 * C + c] = -sc * m2 * rstd;
-        save[6 * C + c] = -sc * m1;
-    }
+    if (lane == 0) { part[wid][0] = s1; part[wid][1] = s2; }
+    __syncthreads();
+    if (tid != 0) return;
+#pragma unroll
+    for (int w = 1; w < BNV_THREADS / 64; ++w) { s1 += part[w][0]; s2 += part[w][1]; }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+    const float m1 = s1 / (float)n, m2 = s2 / (float)n;
+    const float rstd = save[C + c], sc = save[2 * C + c];
+    save[4 * C + c] = sc;  // dy = sc*(g - m1 - xhat*m2)
+    save[5 * C + c] = -sc * m2 * rstd;
+    save[6 * C + c] = -sc * m1;
 }

@@ -420,15 +420,17 @@ template <int MT, int NT>
 static void launch_wgrad_inst(const Ctx& c, const WgArgs& wa, int grid, size_t bytes) {
     hipLaunchKernelGGL((igemm_wgrad_k<MT, NT>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
 }
-static int wgrad_grid(int nchunks) {
-    const int wg_max = IG_WG_MAX_GRID;
+// kernels with <= 5 accumulator tiles fit two workgroups per CU; the fat ones only one, and their
+// per-workgroup reduction is expensive: fewer, longer-lived workgroups
+static int wgrad_grid(const WgPlan& wp, int nchunks) {
+    const int wg_max = wp.MT * wp.NT <= 5 ? IG_WG_MAX_GRID : IG_WG_MAX_GRID / 2;
     return nchunks < wg_max ? nchunks : wg_max;
 }
 static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
-    return (int64_t)wgrad_grid((B + wp.SB - 1) / wp.SB) * (wp.MT * wp.NT * 256 + 64);
+    return (int64_t)wgrad_grid(wp, (B + wp.SB - 1) / wp.SB) * (wp.MT * wp.NT * 256 + 64);
 }
 static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float* dw, float* db) {
-    const int grid = wgrad_grid(wa.nchunks);
+    const int grid = wgrad_grid(wp, wa.nchunks);
     const size_t bytes = (size_t)wp.total * sizeof(float);
     switch (wp.MT * 100 + wp.NT) {
         case 101: launch_wgrad_inst<1, 1>(c, wa, grid, bytes); break;
@@ -443,7 +445,7 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
     }
     VAE_LAUNCH_CHECK("igemm_wgrad_k");
     const int T = wp.MT * wp.NT;
-    hipLaunchKernelGGL(wgrad_finalize_k, dim3(T * 8 + 2), dim3(256), 0, c.s, wa.part, grid, wp.NT, T, wa.Sc,
+    hipLaunchKernelGGL(wgrad_finalize_k, dim3(T * 16 + 4), dim3(256), 0, c.s, wa.part, grid, wp.NT, T, wa.Sc,
                        wa.Gc * wa.KH * wa.KW, dw, db, wa.bias_from_S ? wa.Sc : wa.Gc);
     VAE_LAUNCH_CHECK("wgrad_finalize_k");
     return VAE_OK;
@@ -640,7 +642,7 @@ static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
     const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
     if (!ok) return VAE_EINVAL;
     if (training && nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no producer statistics");
-    hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(64), 0, c.s, slab, nblocks, gamma, beta, save, rm, rv, C,
+    hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, gamma, beta, save, rm, rv, C,
                        op.f[0], op.f[1], training);
     VAE_LAUNCH_CHECK("bnv_finalize_fwd_k");
     c.last_blocks = 0;
@@ -656,7 +658,7 @@ static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
     const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
     if (!ok) return VAE_EINVAL;
     if (nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no consumer gradient statistics");
-    hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(64), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
+    hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
                        (int64_t)c.B * HW);
     VAE_LAUNCH_CHECK("bnv_finalize_bwd_k");
     c.last_blocks = 0;
