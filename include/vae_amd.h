@@ -117,6 +117,22 @@ int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int
                     int n_bases, int B, int training, vae_stream_t stream);
 int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                      int n_bases, int B, vae_stream_t stream);
+/* Profiling twin of vae_run_forward: a HIP event is recorded on `stream` before every op and after the
+ * last one; op_ms[i] (n_ops floats, host memory) receives the device time of op i in milliseconds.
+ * Synchronises the stream, so it cannot be captured.  bench.py measures the dominant kernel with it. */
+int vae_time_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                     int n_bases, int B, int training, vae_stream_t stream, float* op_ms);
+
+/* Data parallelism (one process per GPU).  The reference is single-device: with equal shards,
+ * gradient all-reduce SUM (done by the host on the flat GRAD buffer) plus synchronised BatchNorm statistics
+ * reproduce its result at the global batch.  For the latter the executor calls `fn` at every training-mode
+ * BatchNorm, forward and backward: buf holds `world` rows of floats_per_rank floats, row `rank` is filled;
+ * fn must all-gather in place, ordered after the work already enqueued on `stream` and before what is
+ * enqueued next (torch.distributed on the current stream does that).  Returns 0 on success.
+ * world <= 1 or fn == NULL switches back to single-GPU statistics.  Process-global; not capturable. */
+#define VAE_MAX_WORLD 64
+typedef int (*vae_allgather_fn)(void* user, float* buf, int64_t floats_per_rank, vae_stream_t stream);
+int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world);
 
 /* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
  * the Python program builder; no GPU needed). */

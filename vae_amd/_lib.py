@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvae_amd.so")
 OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
-MAX_CHUNKS, ELBO_BLOCKS = 64, 1024
+MAX_CHUNKS, ELBO_BLOCKS, MAX_WORLD = 64, 1024, 64
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
 
 
@@ -47,7 +47,10 @@ def lib():
     L.vae_last_error.argtypes = []
     L.vae_check_device.argtypes = []
     L.vae_run_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp]
+    L.vae_time_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp,
+                                   ctypes.POINTER(ctypes.c_float)]
     L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
+    L.vae_set_collective.argtypes = [ALLGATHER_FN, vp, i32, i32]
     L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.restype = i64
@@ -59,15 +62,18 @@ def lib():
     L.vae_graph_end.argtypes = [ctypes.POINTER(vp)]
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
-    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_run_forward", "vae_run_backward", "vae_elbo_forward", "vae_elbo_backward",
-                 "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end", "vae_graph_launch",
+    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_set_collective", "vae_elbo_forward",
+                 "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end", "vae_graph_launch",
                  "vae_graph_destroy"):
         getattr(L, name).restype = i32
     _lib = L
     return L
 
 
-EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_scratch_floats", "vae_run_forward", "vae_run_backward", "vae_elbo_forward",
+# int fn(void* user, float* buf, int64 floats_per_rank, void* stream)  (include/vae_amd.h: vae_allgather_fn)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_scratch_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_elbo_forward",
            "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ x
 // like torch: running = (1-m)*running + m*stat, with the UNBIASED variance for running_var.
 __global__ void bn_stats_finalize_k(const float* __restrict__ x, const float* __restrict__ partials,
                                     float* __restrict__ save, float* __restrict__ rmean, float* __restrict__ rvar,
-                                    int C, int HW, int nchunks, int64_t n, float eps, float momentum) {
+                                    int C, int HW, int nchunks, int64_t n, float eps, float momentum,
+                                    float* __restrict__ row_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
@@ -81,6 +82,13 @@ __global__ void bn_stats_finalize_k(const float* __restrict__ x, const float* __
     const float inv_n = 1.f / (float)n;
     const float dm = s1 * inv_n;
     const float mean = pivot + dm;
+    if (row_out != nullptr) {  // data-parallel: this rank's {mean, -, M2, n} row (merged by bnv_finalize_fwd_k)
+        row_out[c * 4] = mean;
+        row_out[c * 4 + 1] = 0.f;
+        row_out[c * 4 + 2] = fmaxf(s2 - s1 * dm, 0.f);
+        row_out[c * 4 + 3] = (float)n;
+        return;
+    }
     float var = s2 * inv_n - dm * dm;
     var = var > 0.f ? var : 0.f;
     save[c] = mean;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, f
 // sum over chunks -> dgamma = sum(g*xhat), dbeta = sum(g); save[2C:3C] = sum(g)/n, save[3C:4C] = sum(g*xhat)/n
 __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, float* __restrict__ save,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int nchunks,
-                                  int64_t n) {
+                                  int64_t n, float* __restrict__ row_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
@@ -125,10 +133,36 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, float* __r
         s1 += partials[((int64_t)k * C + c) * 2];
         s2 += partials[((int64_t)k * C + c) * 2 + 1];
     }
+    if (row_out != nullptr) {  // data-parallel: this rank's {sum g, sum g*xhat, n} row
+        row_out[c * 4] = s1;
+        row_out[c * 4 + 1] = s2;
+        row_out[c * 4 + 2] = (float)n;
+        row_out[c * 4 + 3] = 0.f;
+        return;
+    }
     dbeta[c] = s1;
     dgamma[c] = s2;
     save[2 * C + c] = s1 / (float)n;
     save[3 * C + c] = s2 / (float)n;
+}
+
+// Data-parallel second pass: rows[rank][c] = {sum g, sum g*xhat, n} of every rank.  The means are global,
+// dgamma/dbeta stay this rank's local sums (the gradient all-reduce adds the ranks).
+__global__ void bn_bwd_rows_k(const float* __restrict__ rows, int world, const float* __restrict__ local_row,
+                              float* __restrict__ save, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                              int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f, n = 0.f;
+    for (int r = 0; r < world; ++r) {
+        s1 += rows[((int64_t)r * C + c) * 4];
+        s2 += rows[((int64_t)r * C + c) * 4 + 1];
+        n += rows[((int64_t)r * C + c) * 4 + 2];
+    }
+    dbeta[c] = local_row[c * 4];
+    dgamma[c] = local_row[c * 4 + 1];
+    save[2 * C + c] = s1 / n;
+    save[3 * C + c] = s2 / n;
 }
 
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g*xhat));  g already ReLU-masked in dout.
@@ -151,32 +185,4 @@ __global__ void bias_grad_finalize_k(const float* __restrict__ partials, float* 
     float s = 0.f;
     for (int k = 0; k < nchunks; ++k) s += partials[((int64_t)k * C + c) * 2];
     db[c] = s;
-}
-
-// Row-major [B][N] (ld) matrices: g = dy * act'(y) in place, db[n] = column sums.
-// grid.x = column tiles of 64, grid.y = row chunks; partials[chunk][n][2] like chan_reduce_k.
-__global__ __launch_bounds__(256) void col_actbwd_reduce_k(float* __restrict__ dy, const float* __restrict__ y,
-                                                           float* __restrict__ partials, int B, int N, int ld_dy,
-                                                           int ld_y, int bchunk, int act, float slope) {
-    __shared__ float sm[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rsub = threadIdx.x >> 6;  // 4 row phases
-    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
-    float s = 0.f;
-    if (col < N) {
-        for (int b = b0 + rsub; b < b1; b += 4) {
-            float g = dy[(int64_t)b * ld_dy + col];
-            if (act != VAE_ACT_NONE) {
-                g *= act_grad_from_out(y[(int64_t)b * ld_y + col], act, slope);
-                dy[(int64_t)b * ld_dy + col] = g;
-            }
-            s += g;
-        }
-    }
-    sm[rsub][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (threadIdx.x < 64 && col < N) {
-        const float t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-        partials[((int64_t)blockIdx.y * N + col) * 2] = t;
-    }
 }

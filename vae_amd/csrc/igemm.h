@@ -77,6 +77,7 @@ struct IgGeom {
 // contribute and where its tap table / weight image start in LDS.  Filled on the host.
 struct IgClass {
     int rh, rw, AH, AW, kh0, kw0, nkh, nkw, ntaps, Kc, KcPad, toff, woff;
+    int poff;  // start of the class in the pixel table (filled at launch: SB * pixels of the earlier classes)
     FastDiv d_ntaps, d_nkw, d_AHW, d_AW;
 };
 
@@ -97,7 +98,7 @@ struct IgArgs {
     float* slab;              // per-block per-channel {pivot, s1, s2, count} (forward statistics) or
                               // {s1, s2, -, -} (backward sums), or nullptr
     // LDS carve (floats)
-    int lds_in, lds_w, lds_out, lds_tab;
+    int lds_in, lds_w, lds_out, lds_tab, lds_ptab;
     int ncls, nchunks;
     int pre;  // 1: chunks fit the register prefetch (<= IG_PRE*IG_THREADS input elements)
     FastDiv d_N, d_ntile;  // by N and by Np/16
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     float* lw = lin + a.lds_in;
     float* lout = lw + a.lds_w;
     int* ktab = reinterpret_cast<int*>(lout + a.lds_out);
-    float* cin = reinterpret_cast<float*>(ktab + a.lds_tab);  // [8*Cin] input transform coefficients
+    uint32_t* ptab = reinterpret_cast<uint32_t*>(ktab + a.lds_tab);  // per class pixel: in offset | out offset << 16
+    float* cin = reinterpret_cast<float*>(ptab + a.lds_ptab);  // [8*Cin] input transform coefficients
     float* cep = cin + 8 * g.Cin;                             // [8*N]   epilogue (producer BN) coefficients
     float* lbias = cep + 8 * g.N;                             // [Np]    bias (zero padded)
 
@@ -245,8 +247,18 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     ig_load_coef(a.in.coef, cin, 8 * g.Cin);
     ig_load_coef(a.ep_coef, cep, 8 * g.N);
     for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
+    float* const dummy = lbias + g.Np;  // spare LDS word: masked-off epilogue stores land here
     for (int cls = 0; cls < a.ncls; ++cls) {
         const IgClass& c = a.cls[cls];
+        // pixel table (chunk-invariant): class pixel q -> offsets of its window in lin and of its output in lout
+        const int AHWc = c.AH * c.AW;
+        for (int q = tid; q < a.SB * AHWc; q += IG_THREADS) {
+            const int s = fdiv((uint32_t)q, c.d_AHW), rem = q - s * AHWc;
+            const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
+            const uint32_t io = s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
+            const uint32_t oo = s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw;
+            ptab[c.poff + q] = io | (oo << 16);
+        }
         const int nw = c.KcPad * g.Np;
         for (int base = tid; base < nw; base += IG_THREADS * 4) {  // four independent weight loads in flight
             float v[4];
@@ -316,11 +328,9 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 for (int i = 0; i < TI; ++i) {
                     const int q = (t0 + i * IG_WAVES) * 16 + li;
                     const bool valid = q < P;
-                    const int qq = valid ? q : 0;
-                    const int s = fdiv((uint32_t)qq, c.d_AHW), rem = qq - s * AHW;
-                    const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
-                    lp[i] = lin + s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
-                    outoff[i] = valid ? s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw : -1;
+                    const uint32_t pe = ptab[c.poff + (valid ? q : 0)];
+                    lp[i] = lin + (pe & 0xffffu);
+                    outoff[i] = valid ? (int)(pe >> 16) : -1;
                 }
                 const int* kt = ktab + c.toff + lk;
                 for (int nc = 0; nc < n_ntile; nc += NT) {
@@ -362,9 +372,10 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                             for (int r = 0; r < 4; ++r) {
                                 const float bv = lbias[n0 + r];
 #pragma unroll
-                                for (int i = 0; i < TI; ++i)
-                                    if (outoff[i] >= 0 && n0 + r < g.N)
-                                        lout[outoff[i] + (n0 + r) * OHW] = acc[i][j][r] + bv;
+                                for (int i = 0; i < TI; ++i) {  // branch-free: masked lanes write the spare word
+                                    float* dst = (outoff[i] >= 0 && n0 + r < g.N) ? lout + outoff[i] + (n0 + r) * OHW : dummy;
+                                    *dst = acc[i][j][r] + bv;
+                                }
                             }
                         }
                     }
@@ -683,7 +694,8 @@ __global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_fwd_k(const float* _
                                                                   const float* __restrict__ beta,
                                                                   float* __restrict__ save, float* __restrict__ rmean,
                                                                   float* __restrict__ rvar, int C, float eps,
-                                                                  float momentum, int training) {
+                                                                  float momentum, int training,
+                                                                  float* __restrict__ row_out) {
     __shared__ float part[BNV_THREADS / 64][3];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float mean, var;
@@ -713,6 +725,10 @@ __global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_fwd_k(const float* _
         if (tid != 0) return;
 #pragma unroll
         for (int w = 1; w < BNV_THREADS / 64; ++w) chan_merge(n, mu, m2, part[w][0], part[w][1], part[w][2]);
+        if (row_out != nullptr) {  // data-parallel: this rank's (n, mean, M2) as one slab row for the all-gather
+            *reinterpret_cast<float4*>(row_out + (int64_t)c * 4) = make_float4(mu, 0.f, m2, n);
+            return;
+        }
         mean = mu;
         var = n > 0.f ? m2 / n : 0.f;
         const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
@@ -732,28 +748,46 @@ __global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_fwd_k(const float* _
 // backward: slab of {sum g, sum g*xhat} -> dgamma, dbeta and (a, b, c) of dy = a*g + b*(y-mean) + c
 __global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_bwd_k(const float* __restrict__ slab, int nblocks,
                                                                   float* __restrict__ save, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta, int C, int64_t n) {
-    __shared__ float part[BNV_THREADS / 64][2];
+                                                                  float* __restrict__ dbeta, int C, int64_t n_local,
+                                                                  float* __restrict__ row_out,
+                                                                  const float* __restrict__ local_row) {
+    // single GPU: slab rows are workgroup partials, n = n_local.  Data-parallel, pass 1 (row_out): this
+    // rank's sums + its count as one row; pass 2 (local_row): rows are ranks, n = sum of their counts, and
+    // dgamma/dbeta stay this rank's LOCAL sums (the gradient all-reduce adds the ranks up).
+    __shared__ float part[BNV_THREADS / 64][3];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, cnt = 0.f;
     for (int k = tid; k < nblocks; k += BNV_THREADS) {
-        const float2 sl = *reinterpret_cast<const float2*>(slab + ((int64_t)k * C + c) * 4);
+        const float4 sl = *reinterpret_cast<const float4*>(slab + ((int64_t)k * C + c) * 4);
         s1 += sl.x;
         s2 += sl.y;
+        cnt += sl.z;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         s1 += __shfl_xor(s1, off, 64);
         s2 += __shfl_xor(s2, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
     }
-    if (lane == 0) { part[wid][0] = s1; part[wid][1] = s2; }
+    if (lane == 0) { part[wid][0] = s1; part[wid][1] = s2; part[wid][2] = cnt; }
     __syncthreads();
     if (tid != 0) return;
 #pragma unroll
-    for (int w = 1; w < BNV_THREADS / 64; ++w) { s1 += part[w][0]; s2 += part[w][1]; }
-    dbeta[c] = s1;
-    dgamma[c] = s2;
-    const float m1 = s1 / (float)n, m2 = s2 / (float)n;
+    for (int w = 1; w < BNV_THREADS / 64; ++w) { s1 += part[w][0]; s2 += part[w][1]; cnt += part[w][2]; }
+    if (row_out != nullptr) {
+        *reinterpret_cast<float4*>(row_out + (int64_t)c * 4) = make_float4(s1, s2, (float)n_local, 0.f);
+        return;
+    }
+    float n = (float)n_local;
+    if (local_row != nullptr) {
+        n = cnt;
+        dbeta[c] = local_row[c * 4];
+        dgamma[c] = local_row[c * 4 + 1];
+    } else {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+    }
+    const float m1 = s1 / n, m2 = s2 / n;
     const float rstd = save[C + c], sc = save[2 * C + c];
     save[4 * C + c] = sc;  // dy = sc*(g - m1 - xhat*m2)
     save[5 * C + c] = -sc * m2 * rstd;

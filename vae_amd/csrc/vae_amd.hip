@@ -7,7 +7,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-#include <stdlib.h>
 
 #include "chan.h"
 #include "common.h"
@@ -36,6 +35,11 @@ extern "C" int vae_check_device(void) {
 }
 
 // ---- reference resolution ------------------------------------------------------------------
+// Data-parallel hook (vae_set_collective): SyncBN all-gathers one slab row per rank through it.
+static vae_allgather_fn g_allgather = nullptr;
+static void* g_allgather_user = nullptr;
+static int g_rank = 0, g_world = 1;
+
 struct Ctx {
     float* const* bases;
     const int64_t* sizes;
@@ -239,14 +243,12 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 
 
 // ---- fused implicit-GEMM conv path (igemm.h) ------------------------------------------------
-static int tune(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#define IG_LDS_BUDGET_FLOATS tune("VAE_T_LDS", 16000)  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
-#define IG_WG_LDS_BUDGET tune("VAE_T_WGLDS", 16000)
-#define IG_WG_MAX_GRID tune("VAE_T_WGGRID", 512)          // wgrad: 1 workgroup per CU (its accumulators need ~180 VGPRs); few, fat
-                                    // workgroups also keep the global atomics on dw/dbias rare
-#define IG_MAX_GRID tune("VAE_T_GRID", 512)            // persistent workgroups (up to 4 per CU), each loops over its chunks
-#define IG_SB_TARGET tune("VAE_T_SBT", 1024)
-#define IG_WG_SB_TARGET tune("VAE_T_WGSBT", 1024)
+#define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
+#define IG_WG_LDS_BUDGET 16000
+#define IG_MAX_GRID 512     // gather: persistent workgroups, two resident per CU, each loops over its chunks
+#define IG_WG_MAX_GRID 512  // wgrad: same for kernels with <= 5 accumulator tiles, half of it for the fat ones
+#define IG_SB_TARGET 1024   // chunk = ceil(B / target) samples (bounded by the LDS budget and the prefetch registers)
+#define IG_WG_SB_TARGET 1024
 
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
@@ -302,7 +304,7 @@ static IgGeom make_geom(int transposed, int Cin, int H, int W, int N, int OH, in
 }
 
 struct IgPlan {
-    int SB, lds_in, lds_w, lds_out, lds_tab, total, pre;
+    int SB, lds_in, lds_w, lds_out, lds_tab, lds_ptab, total, pre;
 };
 // Host mirror of the per-class tap enumeration (igemm.h IgClass); returns the class count.
 static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
@@ -343,7 +345,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     int wsum = 0, tsum = 0;
     if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
     fill_classes(g, cls, &wsum, &tsum);
-    const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW;
+    const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW + g.OH * g.OW;  // (+ pixel table)
     const int coef = 8 * (g.Cin + g.N) + g.Np + 8;
     const int fixed = wsum + tsum + coef;
     int fit = (IG_LDS_BUDGET_FLOATS - fixed) / (per_in + per_out);
@@ -360,8 +362,10 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
         if (p.pre && sb > cap) sb = cap;
     }
     p.SB = sb;
-    p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * per_out; p.lds_tab = tsum;
-    p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + coef;
+    p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * g.N * g.OH * g.OW; p.lds_tab = tsum;
+    p.lds_ptab = sb * g.OH * g.OW;
+    p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + p.lds_ptab + coef;
+    if (p.lds_in >= 65536 || p.lds_out >= 65536) p.SB = 0;  // the pixel table packs two 16-bit LDS offsets
     // FastDiv exactness bound: n * d < 2^32 for every (n, d) pair the kernels divide
     const uint64_t nmax = (uint64_t)(p.lds_in > p.lds_out ? p.lds_in : p.lds_out) + wsum;
     if (nmax * (uint64_t)(g.Cin * g.H * g.W + g.N * g.OH * g.OW + 1) >= ((uint64_t)1 << 32)) p.SB = 0;
@@ -462,6 +466,16 @@ static int conv_igemm_fits(const vae_op& op, int B) {
     return plan_gather(f, B).SB >= 1 && plan_gather(d, B).SB >= 1 && w.SB >= 1 && g.sh <= 2 && g.sw <= 2;
 }
 
+extern "C" int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world) {
+    if (fn == nullptr || world <= 1) {
+        g_allgather = nullptr; g_allgather_user = nullptr; g_rank = 0; g_world = 1;
+        return VAE_OK;
+    }
+    if (world > VAE_MAX_WORLD || rank < 0 || rank >= world) VAE_FAIL(VAE_EINVAL, "set_collective: bad rank %d / world %d", rank, world);
+    g_allgather = fn; g_allgather_user = user; g_rank = rank; g_world = world;
+    return VAE_OK;
+}
+
 extern "C" int64_t vae_conv_scratch_floats(const vae_op* op, int B) {
     if (op == nullptr || (op->kind != VAE_OP_CONV && op->kind != VAE_OP_CONVT) || B < 1) return 0;
     if (check_geom(*op) != VAE_OK) return 0;
@@ -470,7 +484,8 @@ extern "C" int64_t vae_conv_scratch_floats(const vae_op* op, int B) {
     const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     if (w.SB < 1) return 0;
-    const int64_t slab = (int64_t)4 * (g.Cin > g.Cout ? g.Cin : g.Cout) * B;  // BatchNorm slabs: <= one row per sample
+    // BatchNorm slabs: <= one row per sample, plus one gathered row per data-parallel rank
+    const int64_t slab = (int64_t)4 * (g.Cin > g.Cout ? g.Cin : g.Cout) * ((int64_t)B + VAE_MAX_WORLD);
     const int64_t part = wgrad_part_floats(w, B);
     return slab > part ? slab : part;
 }
@@ -485,10 +500,14 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const IgPlan p = plan_gather(a.g, c.B);
     if (p.SB < 1) VAE_FAIL(VAE_EINVAL, "%s: layer does not fit the fused conv kernel's LDS budget", what);
     a.B = c.B; a.SB = p.SB; a.pre = p.pre;
-    a.lds_in = p.lds_in; a.lds_w = p.lds_w; a.lds_out = p.lds_out; a.lds_tab = p.lds_tab;
+    a.lds_in = p.lds_in; a.lds_w = p.lds_w; a.lds_out = p.lds_out; a.lds_tab = p.lds_tab; a.lds_ptab = p.lds_ptab;
     int wsum, tsum;
     a.ncls = fill_classes(a.g, a.cls, &wsum, &tsum);
     a.nchunks = (c.B + p.SB - 1) / p.SB;
+    for (int i = 0, poff = 0; i < a.ncls; ++i) {
+        a.cls[i].poff = poff;
+        poff += p.SB * a.cls[i].AH * a.cls[i].AW;
+    }
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
     const int g_max = IG_MAX_GRID;
@@ -639,11 +658,25 @@ static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
     float* rm = resolve(c, op.r[7], C, "bn.running_mean", &ok);
     float* rv = resolve(c, op.r[8], C, "bn.running_var", &ok);
     const int nblocks = training ? c.last_blocks : 0;
-    const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
+    const bool dp = training && g_world > 1;
+    // data-parallel: the ranks' rows are gathered right behind the local slab
+    float* slab = resolve(c, op.r[9], (int64_t)4 * C * ((nblocks > 0 ? nblocks : 1) + (dp ? g_world : 0)), "bn.slab", &ok);
     if (!ok) return VAE_EINVAL;
     if (training && nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no producer statistics");
-    hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, gamma, beta, save, rm, rv, C,
-                       op.f[0], op.f[1], training);
+    const float* rows = slab;
+    int nrows = nblocks;
+    if (dp) {
+        float* gath = slab + (int64_t)4 * C * nblocks;
+        hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, gamma, beta, save, rm,
+                           rv, C, op.f[0], op.f[1], training, gath + (int64_t)g_rank * 4 * C);
+        VAE_LAUNCH_CHECK("bnv_finalize_fwd_k(local row)");
+        if (g_allgather(g_allgather_user, gath, (int64_t)4 * C, (vae_stream_t)c.s) != 0)
+            VAE_FAIL(VAE_EINVAL, "bn(virtual): the all-gather hook failed");
+        rows = gath;
+        nrows = g_world;
+    }
+    hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, rows, nrows, gamma, beta, save, rm, rv, C,
+                       op.f[0], op.f[1], training, (float*)nullptr);
     VAE_LAUNCH_CHECK("bnv_finalize_fwd_k");
     c.last_blocks = 0;
     return VAE_OK;
@@ -655,11 +688,25 @@ static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
     float* dbeta = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), C, "bn.dbeta", &ok);
     float* save = resolve(c, op.r[6], (int64_t)8 * C, "bn.save", &ok);
     const int nblocks = c.last_blocks;
-    const float* slab = resolve(c, op.r[9], (int64_t)4 * C * (nblocks > 0 ? nblocks : 1), "bn.slab", &ok);
+    const bool dp = g_world > 1;
+    float* slab = resolve(c, op.r[9], (int64_t)4 * C * ((nblocks > 0 ? nblocks : 1) + (dp ? g_world : 0)), "bn.slab", &ok);
     if (!ok) return VAE_EINVAL;
     if (nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no consumer gradient statistics");
-    hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
-                       (int64_t)c.B * HW);
+    const int64_t n_local = (int64_t)c.B * HW;
+    if (dp) {
+        float* gath = slab + (int64_t)4 * C * nblocks;
+        float* mine = gath + (int64_t)g_rank * 4 * C;
+        hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
+                           n_local, mine, (const float*)nullptr);
+        VAE_LAUNCH_CHECK("bnv_finalize_bwd_k(local row)");
+        if (g_allgather(g_allgather_user, gath, (int64_t)4 * C, (vae_stream_t)c.s) != 0)
+            VAE_FAIL(VAE_EINVAL, "bn(virtual): the all-gather hook failed");
+        hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, gath, g_world, save, dgamma, dbeta, C,
+                           n_local, (float*)nullptr, (const float*)mine);
+    } else {
+        hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
+                           n_local, (float*)nullptr, (const float*)nullptr);
+    }
     VAE_LAUNCH_CHECK("bnv_finalize_bwd_k");
     c.last_blocks = 0;
     return VAE_OK;
@@ -668,6 +715,7 @@ static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
 // ---- batch norm -----------------------------------------------------------------------------
 static int bn_forward(const Ctx& c, const vae_op& op, int training) {
     const int C = op.d[0], HW = op.d[1];
+
     if (C < 1 || HW < 1) VAE_FAIL(VAE_EINVAL, "bn: bad shape C=%d HW=%d", C, HW);
     const int64_t total = (int64_t)c.B * C * HW;
     if (training && (int64_t)c.B * HW < 2)
@@ -688,9 +736,22 @@ static int bn_forward(const Ctx& c, const vae_op& op, int training) {
         hipLaunchKernelGGL(chan_reduce_k<CR_STATS>, dim3(C, nchunks), dim3(256), 0, c.s, x, nullptr, nullptr, nullptr,
                            part, c.B, C, HW, bchunk, 0, 0.f, 0);
         VAE_LAUNCH_CHECK("chan_reduce_k<STATS>");
-        hipLaunchKernelGGL(bn_stats_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, x, part, save, rm, rv, C, HW,
-                           nchunks, (int64_t)c.B * HW, op.f[0], op.f[1]);
-        VAE_LAUNCH_CHECK("bn_stats_finalize_k");
+        if (g_world > 1) {  // data-parallel: one {mean, -, M2, n} row per rank behind the partials, then a merge
+            float* gath = resolve(c, op.r[9] + (int64_t)2 * C * VAE_MAX_CHUNKS, (int64_t)4 * C * g_world, "bn.rows", &ok);
+            if (!ok) return VAE_EINVAL;
+            hipLaunchKernelGGL(bn_stats_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, x, part, save, rm, rv, C, HW,
+                               nchunks, (int64_t)c.B * HW, op.f[0], op.f[1], gath + (int64_t)g_rank * 4 * C);
+            VAE_LAUNCH_CHECK("bn_stats_finalize_k(local row)");
+            if (g_allgather(g_allgather_user, gath, (int64_t)4 * C, (vae_stream_t)c.s) != 0)
+                VAE_FAIL(VAE_EINVAL, "bn: the all-gather hook failed");
+            hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, gath, g_world, gamma, beta, save, rm,
+                               rv, C, op.f[0], op.f[1], 1, (float*)nullptr);
+            VAE_LAUNCH_CHECK("bnv_finalize_fwd_k(rows)");
+        } else {
+            hipLaunchKernelGGL(bn_stats_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, x, part, save, rm, rv, C, HW,
+                               nchunks, (int64_t)c.B * HW, op.f[0], op.f[1], (float*)nullptr);
+            VAE_LAUNCH_CHECK("bn_stats_finalize_k");
+        }
     } else {
         hipLaunchKernelGGL(bn_eval_prepare_k, dim3((C + 63) / 64), dim3(64), 0, c.s, rm, rv, save, C, op.f[0]);
         VAE_LAUNCH_CHECK("bn_eval_prepare_k");
@@ -720,9 +781,22 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
     hipLaunchKernelGGL(chan_reduce_k<CR_BNBWD>, dim3(C, nchunks), dim3(256), 0, c.s, x, dy, y, save, part, c.B, C, HW,
                        bchunk, 0, 0.f, (op.flags & VAE_F_BN_RELU) ? 1 : 0);
     VAE_LAUNCH_CHECK("chan_reduce_k<BNBWD>");
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, part, save, dgamma, dbeta, C, nchunks,
-                       (int64_t)c.B * HW);
-    VAE_LAUNCH_CHECK("bn_bwd_finalize_k");
+    if (g_world > 1) {
+        float* gath = resolve(c, op.r[9] + (int64_t)2 * C * VAE_MAX_CHUNKS, (int64_t)4 * C * g_world, "bn.rows", &ok);
+        if (!ok) return VAE_EINVAL;
+        float* mine = gath + (int64_t)g_rank * 4 * C;
+        hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, part, save, dgamma, dbeta, C,
+                           nchunks, (int64_t)c.B * HW, mine);
+        VAE_LAUNCH_CHECK("bn_bwd_finalize_k(local row)");
+        if (g_allgather(g_allgather_user, gath, (int64_t)4 * C, (vae_stream_t)c.s) != 0)
+            VAE_FAIL(VAE_EINVAL, "bn: the all-gather hook failed");
+        hipLaunchKernelGGL(bn_bwd_rows_k, dim3((C + 63) / 64), dim3(64), 0, c.s, gath, g_world, mine, save, dgamma, dbeta, C);
+        VAE_LAUNCH_CHECK("bn_bwd_rows_k");
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(64), 0, c.s, part, save, dgamma, dbeta, C,
+                           nchunks, (int64_t)c.B * HW, (float*)nullptr);
+        VAE_LAUNCH_CHECK("bn_bwd_finalize_k");
+    }
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(total)), dim3(256), 0, c.s, x, dy, dx, save, gamma, total, C, HW);
     VAE_LAUNCH_CHECK("bn_bwd_apply_k");
     return VAE_OK;
@@ -936,27 +1010,51 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     return VAE_OK;
 }
 
+static int forward_op(const Ctx& c, const vae_op& op, int i, int training) {
+    switch (op.kind) {
+        case VAE_OP_CONV:
+        case VAE_OP_CONVT: return (op.flags & VAE_F_FUSED) ? conv_forward_fused(c, op, training) : conv_forward(c, op);
+        case VAE_OP_BN: return (op.flags & VAE_F_FUSED) ? bn_virtual_forward(c, op, training) : bn_forward(c, op, training);
+        case VAE_OP_LINEAR: return linear_forward(c, op);
+        case VAE_OP_REPARAM: return reparam_forward(c, op);
+        case VAE_OP_SLICE0: return slice0_forward(c, op);
+        case VAE_OP_ELBO: return elbo_forward(c, op);
+        default: vae_set_error("op %d: unknown kind %d", i, op.kind); return VAE_EINVAL;
+    }
+}
+
 extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                                int n_bases, int B, int training, vae_stream_t stream) {
     Ctx c;
     int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
+    for (int i = 0; i < n_ops && rc == VAE_OK; ++i) rc = forward_op(c, ops[i], i, training);
+    return rc;
+}
+
+// Same launches as vae_run_forward with a HIP event between consecutive ops ON THE LAUNCH STREAM; fills
+// op_ms[i] with the device time of op i.  Synchronises the stream; not capturable.
+extern "C" int vae_time_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                                int n_bases, int B, int training, vae_stream_t stream, float* op_ms) {
+    if (op_ms == nullptr || n_ops < 1 || n_ops > 4096) VAE_FAIL(VAE_EINVAL, "time_forward: bad arguments");
+    Ctx c;
+    int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
+    if (rc) return rc;
+    hipEvent_t* ev = new hipEvent_t[n_ops + 1];
+    int made = 0;
+    for (; made <= n_ops; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) break;
+    if (made <= n_ops) rc = VAE_EHIP, vae_set_error("time_forward: hipEventCreate failed");
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
-        const vae_op& op = ops[i];
-        switch (op.kind) {
-            case VAE_OP_CONV:
-            case VAE_OP_CONVT:
-                rc = (op.flags & VAE_F_FUSED) ? conv_forward_fused(c, op, training) : conv_forward(c, op);
-                break;
-            case VAE_OP_BN:
-                rc = (op.flags & VAE_F_FUSED) ? bn_virtual_forward(c, op, training) : bn_forward(c, op, training);
-                break;
-            case VAE_OP_LINEAR: rc = linear_forward(c, op); break;
-            case VAE_OP_REPARAM: rc = reparam_forward(c, op); break;
-            case VAE_OP_SLICE0: rc = slice0_forward(c, op); break;
-            case VAE_OP_ELBO: rc = elbo_forward(c, op); break;
-            default: vae_set_error("op %d: unknown kind %d", i, op.kind); rc = VAE_EINVAL;
-        }
+        if (hipEventRecord(ev[i], c.s) != hipSuccess) { rc = VAE_EHIP; vae_set_error("hipEventRecord failed"); break; }
+        rc = forward_op(c, ops[i], i, training);
     }
+    if (rc == VAE_OK && (hipEventRecord(ev[n_ops], c.s) != hipSuccess || hipEventSynchronize(ev[n_ops]) != hipSuccess))
+        rc = VAE_EHIP, vae_set_error("time_forward: event record/synchronize failed");
+    for (int i = 0; i < n_ops && rc == VAE_OK; ++i)
+        if (hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]) != hipSuccess)
+            rc = VAE_EHIP, vae_set_error("hipEventElapsedTime failed");
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
     return rc;
 }
 

@@ -1,0 +1,138 @@
+"""Data parallelism for the VAE train step: one process per GPU over torch.distributed.
+
+The reference is single-device.  Samples are independent except through train-mode
+BatchNorm, and the ELBO is a SUM over samples (train.py:41-48), so a step on W equal batch shards
+equals the single-GPU step on the global batch when
+
+  * every training-mode BatchNorm uses the statistics of the global batch, forward and backward
+    (the executor all-gathers one row of per-channel sums per rank through `vae_set_collective`), and
+  * the flat gradient buffer is all-reduced with SUM (not mean) before Adam.
+
+Parameters, Adam state and BatchNorm running statistics are replicated and stay bit-identical across
+ranks because every rank applies the same update.  eps is drawn per rank from a rank-offset seed.
+backend "nccl" is RCCL on ROCm; "gloo" (CPU tensors, or GPU tensors staged through the host) serves
+the CPU tests and single-GPU rehearsals.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .train import FusedTrainStep
+
+
+def shard_bounds(global_batch, rank, world):
+    """[lo, hi) of the contiguous shard of `rank`; the first global_batch % world ranks get one more."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} / world {world}")
+    q, r = divmod(global_batch, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class Collective:
+    """The two exchanges of the data-parallel step on a torch.distributed group."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("vae_amd.parallel needs torch.distributed.init_process_group() first")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def _staged(self, t):
+        return t.is_cuda and self.backend == "gloo"
+
+    def all_gather_rows(self, rows):
+        """rows: contiguous (world, n) tensor whose row `rank` is filled; fills the others in place."""
+        if rows.shape[0] != self.world or not rows.is_contiguous():
+            raise ValueError(f"all_gather_rows: expected a contiguous ({self.world}, n) tensor, got {tuple(rows.shape)}")
+        if self._staged(rows):
+            mine = rows[self.rank].cpu()
+            out = torch.empty(rows.numel(), dtype=rows.dtype)
+            dist.all_gather_into_tensor(out, mine.view(-1), group=self.group)
+            rows.copy_(out.view(rows.shape))
+        elif rows.is_cuda:
+            dist.all_gather_into_tensor(rows.view(-1), rows[self.rank].view(-1), group=self.group)  # in place (RCCL allows it)
+        else:
+            mine = rows[self.rank].clone()
+            dist.all_gather_into_tensor(rows.view(-1), mine.view(-1), group=self.group)
+        return rows
+
+    def all_reduce_sum(self, t):
+        """In-place SUM over the ranks (the loss is reduction='sum', so gradients add, not average)."""
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class DataParallelTrainStep(FusedTrainStep):
+    """FusedTrainStep on this rank's shard with synchronised BatchNorm and a gradient all-reduce.
+
+    `B` is the per-rank batch.  The step is enqueued eagerly on the current stream (collectives are
+    not captured): randn, forward (+ one all-gather of 4*C floats per BatchNorm), ELBO, backward
+    (+ one all-gather per BatchNorm), all-reduce SUM of the flat gradient buffer (one bucket: 413 KB for
+    the MNIST model), Adam.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
+
+    def __init__(self, model, optimizer, B, device, bce=None, group=None):
+        super().__init__(model, optimizer, B, device, bce=bce, use_graph=False)
+        self.coll = Collective(group)
+        if self.coll.world > L.MAX_WORLD:
+            raise ValueError(f"world size {self.coll.world} > {L.MAX_WORLD}")
+        # parameters must start identical: rank 0's copy wins (state too)
+        for t in (self.flat, self.sflat):
+            if t.numel():
+                self._broadcast(t)
+        self.rng[0] ^= (self.coll.rank + 1) * 0x9E3779B1  # a different eps stream per rank
+        self._hook_error = None
+        self._hook = L.ALLGATHER_FN(self._allgather_hook)  # keep the thunk alive
+
+    def _broadcast(self, t):
+        if self.coll._staged(t):
+            h = t.cpu()
+            dist.broadcast(h, src=0, group=self.coll.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=0, group=self.coll.group)
+
+    def _allgather_hook(self, _user, buf, n, _stream):
+        try:
+            off = (buf - self.work.data_ptr()) // 4
+            if off < 0 or off + self.coll.world * n > self.work.numel():
+                raise RuntimeError("all-gather hook: buffer outside the workspace")
+            self.coll.all_gather_rows(self.work[off:off + self.coll.world * n].view(self.coll.world, n))
+            return 0
+        except Exception as e:  # exceptions cannot cross the C frame: hand it to step()
+            self._hook_error = e
+            return 1
+
+    def _enqueue(self, stream):
+        lib = L.lib()
+        if not self.inject_eps:
+            L.check(lib.vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
+        ext = [self.x.view(self.B, -1), self.eps]
+        L.check(lib.vae_set_collective(self._hook, None, self.coll.rank, self.coll.world), "vae_set_collective")
+        try:
+            self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
+            self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
+        except L.VaeAmdError:
+            if self._hook_error is not None:
+                e, self._hook_error = self._hook_error, None
+                raise e
+            raise
+        finally:
+            lib.vae_set_collective(ctypes.cast(None, L.ALLGATHER_FN), None, 0, 1)
+        self.coll.all_reduce_sum(self.grads)
+        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream)
+
+    def global_loss(self):
+        """Sum of the shard losses of the last step (a host float; synchronises)."""
+        t = self.loss.detach().clone()
+        self.coll.all_reduce_sum(t)
+        return float(t.item())

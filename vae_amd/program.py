@@ -125,7 +125,7 @@ class ProgramBuilder:
                       r=(x.ref, y.ref, x.gref, y.gref, self.param(bn.weight), self.param(bn.bias), save,
                          self.state(bn.running_mean), self.state(bn.running_var)),
                       d=(C, HW), f=(eps, momentum))
-        self._need_scratch(op, 9, 2 * C * L.MAX_CHUNKS)
+        self._need_scratch(op, 9, 2 * C * L.MAX_CHUNKS + 4 * C * L.MAX_WORLD)  # partials + data-parallel rows
         return y
 
     def linear(self, x, w, b, K, N, out=None, act=L.ACT_NONE, acc_din=False, need_din=True):
@@ -233,6 +233,15 @@ class CompiledProgram:
         L.check(L.lib().vae_run_forward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                         1 if training else 0, stream if stream is not None else L.stream_ptr()),
                 "vae_run_forward")
+
+    def time_forward(self, work, params, state, ext, training, stream=None):
+        """Forward with a HIP event between ops on the launch stream; returns per-op device ms (list)."""
+        self._bind(work, params, None, state, ext)
+        ms = (ctypes.c_float * self.n_ops)()
+        L.check(L.lib().vae_time_forward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                         1 if training else 0, stream if stream is not None else L.stream_ptr(), ms),
+                "vae_time_forward")
+        return list(ms)
 
     def backward(self, work, params, grads, state, ext, stream=None):
         self._bind(work, params, grads, state, ext)
