@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 M_FLOP_PER_SAMPLE = 1.89e6
 M_BYTES_PER_SAMPLE = 178e3
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/r01_pmc_*.csv, corrected
+# as DESIGN.md states); None until measured
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 34878259  # (2*8185.6 + 17689.6) KiB, profiles/r01_pmc_summary.csv
 
 
 def cpu_baseline(seconds=15.0, B=4096):
@@ -45,6 +48,41 @@ def cpu_baseline(seconds=15.0, B=4096):
             "sample": f"{n} steps of batch {B} (MNIST VAE fwd+BCE ELBO+bwd+Adam) in {dt:.1f}s, torch CPU threads={cores}"}
 
 
+def dominant_kernel_roofline(stepper, iters):
+    """Roofline of the dominant kernel, igemm_gather_k<1,2,false> (the forward implicit-GEMM gather of every
+    conv / transposed-conv layer with <= 16 output channels: 5 of the 6 conv layers of this model, the
+    largest share of the step in profiles/).  Its launches are timed live with HIP events on the launch
+    stream (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
+    achieved = algorithmic bytes per launch / average launch duration; algorithmic bytes of a launch =
+    4 * B * (Cin*H*W + Cout*OH*OW) + 4 * weights + bias (input read once, output written once: DESIGN.md)."""
+    from vae_amd import _lib as L
+    prog = stepper.prog
+    ext = [stepper.x.view(stepper.B, -1), stepper.eps]
+    sel = []
+    for i in range(prog.n_ops):
+        op = prog.ops[i]
+        if op.kind in (L.OP_CONV, L.OP_CONVT) and (op.flags & L.F_FUSED) and op.d[3] <= 16:
+            cin, H, W, cout, OH, OW, KH, KW = [op.d[j] for j in range(8)]
+            nbytes = 4 * (stepper.B * (cin * H * W + cout * OH * OW) + cin * cout * KH * KW + cout)
+            sel.append((i, nbytes))
+    if not sel:
+        return None
+    tot_ms = [0.0] * len(sel)
+    for it in range(iters + 2):
+        ms = prog.time_forward(stepper.work, stepper.flat, stepper.sflat, ext, True)
+        if it >= 2:
+            for k, (i, _) in enumerate(sel):
+                tot_ms[k] += ms[i]
+    avg_us = sum(tot_ms) / iters / len(sel) * 1e3
+    avg_bytes = sum(b for _, b in sel) / len(sel)
+    achieved = avg_bytes / (avg_us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "kernel": "igemm_gather_k<1, 2, false>",
+            "launches_per_step": len(sel), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": avg_bytes,
+            "per_launch_us": [t / iters * 1e3 for t in tot_ms],
+            "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +91,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--roofline-iters", type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -106,13 +145,13 @@ def main():
     if not (loss == loss) or loss <= 0:
         raise SystemExit(f"loss is {loss}: the step is not training")
 
+    roof = dominant_kernel_roofline(stepper, args.roofline_iters) if rank == 0 else None  # (local launches only)
+    barrier()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         dev_ms = e0.elapsed_time(e1) / args.steps
-        # step-level roofline (materialised-activation traffic model); the per-kernel
-        # figure for the dominant kernel is in DESIGN.md / profiles/
-        achieved = M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9
         line = {
             "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -120,12 +159,15 @@ def main():
             "config": {"workload": ("MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam, "
                                     f"batch {B} per GPU, global batch {B * world}"),
                        "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": "single GPU, whole step as one hipGraph" if world == 1 else f"dp{world} + SyncBN"},
+                       "parallelism": ("single GPU, whole step as one hipGraph" if world == 1 else
+                                       f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM (RCCL)")},
             "loss_per_sample": loss / B,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "scope": "whole step, 178 KB/sample materialised-activation model"},
+            "device_ms_per_step": dev_ms,
+            # whole-step figure against the materialised-activation traffic model of SURVEY 8d (178 KB/sample)
+            "step_hbm_model_GBps": M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9,
         }
+        if roof is not None:
+            line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

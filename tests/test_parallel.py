@@ -55,3 +55,29 @@ def test_dp_hip_path_two_ranks(stem):
     """DataParallelTrainStep (HIP kernels, SyncBN hook, gradient all-reduce) on two ranks sharing the GPU
     reproduces the golden 3-step trajectory of the global batch."""
     _run_world("gpu", stem)
+
+
+@pytest.mark.gpu
+def test_collective_rccl_single_rank():
+    """The RCCL calls DataParallelTrainStep makes (in-place all-gather of workspace rows, all-reduce SUM,
+    broadcast) are accepted by torch.distributed's nccl backend on GPU tensors (world 1: one GPU here)."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "from vae_amd.parallel import Collective\n"
+        "c = Collective()\n"
+        "work = torch.arange(64, dtype=torch.float32, device='cuda')\n"
+        "rows = work[16:48].view(1, 32)\n"
+        "c.all_gather_rows(rows)\n"
+        "g = torch.ones(1000, device='cuda')\n"
+        "c.all_reduce_sum(g)\n"
+        "dist.broadcast(g, src=0)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(work.cpu(), torch.arange(64.)) and float(g.sum()) == 1000.0\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL-OK')\n")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // element happen per WORKGROUP, not per chunk.  The bias gradient is the per-channel sum of the
 // d(pre-activation) tensor, taken from its LDS image (a zero halo adds nothing).
 #define WG_MAXT 20
+#define WG_SMALL_T 2  // kernels with at most this many accumulator tiles fit 128 VGPRs: two workgroups per CU
 
 struct WgArgs {
     TensorIn S, G;
@@ -472,7 +473,7 @@ struct WgArgs {
 // is issued before its first MFMA and the loop has no branches.  Rows m >= Sc and columns
 // n >= Gc*KH*KW read a clamped (valid) row/column; their results are simply never written.
 template <int MT, int NT>
-__global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= 5 ? 4 : 2, MT * NT <= 5 ? 4 : 2))) void igemm_wgrad_k(WgArgs a) {
+__global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= WG_SMALL_T ? 4 : 2, MT * NT <= WG_SMALL_T ? 4 : 2))) void igemm_wgrad_k(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lS = smem;                 // [sb][Sc][SHW]
     float* lG = lS + a.lds_S;         // [sb][Gc][Hp][Wp]

@@ -246,7 +246,7 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 #define IG_LDS_BUDGET_FLOATS 16000  // ~62.5 KiB dynamic LDS: two 512-thread workgroups per CU
 #define IG_WG_LDS_BUDGET 16000
 #define IG_MAX_GRID 512     // gather: persistent workgroups, two resident per CU, each loops over its chunks
-#define IG_WG_MAX_GRID 512  // wgrad: same for kernels with <= 5 accumulator tiles, half of it for the fat ones
+#define IG_WG_MAX_GRID 512  // wgrad: same for kernels with <= WG_SMALL_T accumulator tiles, half of it for the fat ones
 #define IG_SB_TARGET 1024   // chunk = ceil(B / target) samples (bounded by the LDS budget and the prefetch registers)
 #define IG_WG_SB_TARGET 1024
 
@@ -424,10 +424,10 @@ template <int MT, int NT>
 static void launch_wgrad_inst(const Ctx& c, const WgArgs& wa, int grid, size_t bytes) {
     hipLaunchKernelGGL((igemm_wgrad_k<MT, NT>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
 }
-// kernels with <= 5 accumulator tiles fit two workgroups per CU; the fat ones only one, and their
+// kernels with <= WG_SMALL_T accumulator tiles fit two workgroups per CU; the fat ones only one, and their
 // per-workgroup reduction is expensive: fewer, longer-lived workgroups
 static int wgrad_grid(const WgPlan& wp, int nchunks) {
-    const int wg_max = wp.MT * wp.NT <= 5 ? IG_WG_MAX_GRID : IG_WG_MAX_GRID / 2;
+    const int wg_max = wp.MT * wp.NT <= WG_SMALL_T ? IG_WG_MAX_GRID : IG_WG_MAX_GRID / 2;
     return nchunks < wg_max ? nchunks : wg_max;
 }
 static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
