@@ -22,7 +22,7 @@ M_FLOP_PER_SAMPLE = 1.89e6
 M_BYTES_PER_SAMPLE = 178e3
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/r01_pmc_*.csv, corrected
-# as DESIGN.md states); None until measured
+# as DESIGN.md states), measured at batch 4096 per launch (None for any other batch)
 PMC_TRAFFIC_BYTES_PER_LAUNCH = 34878259  # (2*8185.6 + 17689.6) KiB, profiles/r01_pmc_summary.csv
 
 
@@ -77,7 +77,7 @@ def dominant_kernel_roofline(stepper, iters):
     avg_bytes = sum(b for _, b in sel) / len(sel)
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "kernel": "igemm_gather_k<1, 2, false>",
+            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if stepper.B == 4096 else None, "kernel": "igemm_gather_k<1, 2, false>",
             "launches_per_step": len(sel), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": avg_bytes,
             "per_launch_us": [t / iters * 1e3 for t in tot_ms],
             "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
@@ -99,11 +99,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("VAE_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a box with one GPU
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import vae_amd
     from vae_amd.train import FusedTrainStep
@@ -138,7 +143,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(stepper.loss.item())
