@@ -212,7 +212,7 @@ __device__ __forceinline__ void ig_load_coef(const float* g, float* l, int n) {
         for (int i = threadIdx.x; i < n; i += IG_THREADS) l[i] = g[i];
 }
 
-template <int NT, int TI, bool GRAD>
+template <int NT, int TI, bool GRAD, int ND>
 __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_gather_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
@@ -248,51 +248,14 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     ig_load_coef(a.ep_coef, cep, 8 * g.N);
     for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
     float* const dummy = lbias + g.Np;  // spare LDS word: masked-off epilogue stores land here
-    for (int cls = 0; cls < a.ncls; ++cls) {
-        const IgClass& c = a.cls[cls];
-        // pixel table (chunk-invariant): class pixel q -> offsets of its window in lin and of its output in lout
-        const int AHWc = c.AH * c.AW;
-        for (int q = tid; q < a.SB * AHWc; q += IG_THREADS) {
-            const int s = fdiv((uint32_t)q, c.d_AHW), rem = q - s * AHWc;
-            const int ah = fdiv((uint32_t)rem, c.d_AW), aw = rem - ah * c.AW;
-            const uint32_t io = s * CinHpWp + ah * g.si_h * g.Wp + aw * g.si_w;
-            const uint32_t oo = s * g.N * OHW + (ah * g.so_h + c.rh) * g.OW + aw * g.so_w + c.rw;
-            ptab[c.poff + q] = io | (oo << 16);
-        }
-        const int nw = c.KcPad * g.Np;
-        for (int base = tid; base < nw; base += IG_THREADS * 4) {  // four independent weight loads in flight
-            float v[4];
-            int off[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * IG_THREADS;
-                const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
-                const int n = i - k * g.Np;
-                v[u] = 0.f;
-                off[u] = 0;  // k >= Kc: the weight row is zero, any finite in-range operand will do
-                if (i < nw && k < c.Kc) {
-                    const int ci = fdiv((uint32_t)k, c.d_ntaps), ti = k - ci * c.ntaps;
-                    const int i_h = fdiv((uint32_t)ti, c.d_nkw), i_w = ti - i_h * c.nkw;
-                    const int kh = c.kh0 + i_h * g.so_h, kw = c.kw0 + i_w * g.so_w;
-                    int ro = kh, co = kw;
-                    if (g.transposed) {
-                        ro = (c.rh + g.ph - kh) / g.so_h + g.halo_h;
-                        co = (c.rw + g.pw - kw) / g.so_w + g.halo_w;
-                    }
-                    off[u] = ci * HpWp + ro * g.Wp + co;
-                    if (n < g.N) v[u] = a.w[(int64_t)ci * g.w_cstride + (int64_t)n * g.w_nstride + kh * g.KW + kw];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * IG_THREADS;
-                if (i < nw) {
-                    lw[c.woff + i] = v[u];
-                    const int k = fdiv((uint32_t)(i >> 4), a.d_ntile);
-                    if (i == k * g.Np) ktab[c.toff + k] = off[u];
-                }
-            }
-        }
+    if (a.ncls > 1) {
+#define MULTI 1
+#include "igemm_tables.inc"
+#undef MULTI
+    } else {
+#define MULTI 0
+#include "igemm_tables.inc"
+#undef MULTI
     }
 
     for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
@@ -317,6 +280,50 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const IgClass& c = a.cls[cls];
             const int AHW = c.AH * c.AW;
             const int P = sb * AHW;
+            if constexpr (ND > 0) {
+                // Thin layers (<= ND output channels, short K): 16x16 MFMA tiles would be mostly padding and the
+                // fp32 matrix pipe the bottleneck, so every lane takes one output pixel on the vector ALU; the
+                // tap offsets and weights are wave-uniform LDS broadcasts.
+                for (int q = tid; q < P; q += IG_THREADS) {
+                    const uint32_t pe = ptab[c.poff + q];
+                    const float* lp = lin + (pe & 0xffffu);
+                    float* op = lout + (pe >> 16);
+                    float acc[ND];
+#pragma unroll
+                    for (int n = 0; n < ND; ++n) acc[n] = lbias[n];
+                    const int* kt = ktab + c.toff;
+                    const float* wk = lw + c.woff;
+                    // four taps per iteration, every LDS read of the group issued before its first FMA; the
+                    // rows between Kc and its multiple of 4 hold zero weights and in-range offsets
+                    for (int k = 0; k < c.Kc; k += 4) {
+                        const int o0 = kt[k], o1 = kt[k + 1], o2 = kt[k + 2], o3 = kt[k + 3];
+                        const float a0 = lp[o0], a1 = lp[o1], a2 = lp[o2], a3 = lp[o3];
+                        const float* w0 = wk + k * g.Np;
+                        if constexpr (ND == 8) {  // lw is 16-byte aligned (host pads lds_in), rows are 16 floats
+                            const float4* w4 = reinterpret_cast<const float4*>(w0);
+                            const int rs = g.Np >> 2;
+                            const float4 p0 = w4[0], p1 = w4[1], q0 = w4[rs], q1 = w4[rs + 1];
+                            const float4 r0 = w4[2 * rs], r1 = w4[2 * rs + 1], t0 = w4[3 * rs], t1 = w4[3 * rs + 1];
+                            acc[0] = fmaf(a0, p0.x, fmaf(a1, q0.x, fmaf(a2, r0.x, fmaf(a3, t0.x, acc[0]))));
+                            acc[1] = fmaf(a0, p0.y, fmaf(a1, q0.y, fmaf(a2, r0.y, fmaf(a3, t0.y, acc[1]))));
+                            acc[2] = fmaf(a0, p0.z, fmaf(a1, q0.z, fmaf(a2, r0.z, fmaf(a3, t0.z, acc[2]))));
+                            acc[3] = fmaf(a0, p0.w, fmaf(a1, q0.w, fmaf(a2, r0.w, fmaf(a3, t0.w, acc[3]))));
+                            acc[4] = fmaf(a0, p1.x, fmaf(a1, q1.x, fmaf(a2, r1.x, fmaf(a3, t1.x, acc[4]))));
+                            acc[5] = fmaf(a0, p1.y, fmaf(a1, q1.y, fmaf(a2, r1.y, fmaf(a3, t1.y, acc[5]))));
+                            acc[6] = fmaf(a0, p1.z, fmaf(a1, q1.z, fmaf(a2, r1.z, fmaf(a3, t1.z, acc[6]))));
+                            acc[7] = fmaf(a0, p1.w, fmaf(a1, q1.w, fmaf(a2, r1.w, fmaf(a3, t1.w, acc[7]))));
+                        } else {
+#pragma unroll
+                            for (int n = 0; n < ND; ++n)
+                                acc[n] = fmaf(a0, w0[n], fmaf(a1, w0[g.Np + n], fmaf(a2, w0[2 * g.Np + n], fmaf(a3, w0[3 * g.Np + n], acc[n]))));
+                        }
+                    }
+#pragma unroll
+                    for (int n = 0; n < ND; ++n)
+                        if (n < g.N) op[n * OHW] = acc[n];
+                }
+                continue;
+            }
             const int ntile = (P + 15) >> 4;
             // TI tiles in flight per wave: their table -> gather -> MFMA -> store chains are independent,
             // which is what hides the LDS and MFMA latencies (the kernels are latency-, not issue-bound)
@@ -368,13 +375,24 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     for (int j = 0; j < NT; ++j) {
                         const int n0 = (nc + j) * 16 + lk * 4;
                         if (n0 < g.N) {  // (false for a whole padding tile: n0 >= Np)
+                            const float b0 = lbias[n0], b1 = lbias[n0 + 1], b2 = lbias[n0 + 2], b3 = lbias[n0 + 3];
+                            const bool full4 = n0 + 3 < g.N;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float bv = lbias[n0 + r];
-#pragma unroll
-                                for (int i = 0; i < TI; ++i) {  // branch-free: masked lanes write the spare word
-                                    float* dst = (outoff[i] >= 0 && n0 + r < g.N) ? lout + outoff[i] + (n0 + r) * OHW : dummy;
-                                    *dst = acc[i][j][r] + bv;
+                            for (int i = 0; i < TI; ++i) {
+                                // branch-free: a masked pixel writes its four values to the spare word (stride 0)
+                                const bool ok = outoff[i] >= 0;
+                                float* base = ok ? lout + outoff[i] + n0 * OHW : dummy;
+                                const int st = ok ? OHW : 0;
+                                if (full4) {
+                                    base[0] = acc[i][j][0] + b0;
+                                    base[st] = acc[i][j][1] + b1;
+                                    base[2 * st] = acc[i][j][2] + b2;
+                                    base[3 * st] = acc[i][j][3] + b3;
+                                } else {  // channel count not a multiple of 4: per-channel mask
+                                    base[0] = acc[i][j][0] + b0;
+                                    *(n0 + 1 < g.N ? base + st : dummy) = acc[i][j][1] + b1;
+                                    *(n0 + 2 < g.N ? base + 2 * st : dummy) = acc[i][j][2] + b2;
+                                    *(n0 + 3 < g.N ? base + 3 * st : dummy) = acc[i][j][3] + b3;
                                 }
                             }
                         }

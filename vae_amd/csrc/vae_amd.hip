@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "chan.h"
 #include "common.h"
@@ -348,7 +349,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW + g.OH * g.OW;  // (+ pixel table)
     const int coef = 8 * (g.Cin + g.N) + g.Np + 8;
     const int fixed = wsum + tsum + coef;
-    int fit = (IG_LDS_BUDGET_FLOATS - fixed) / (per_in + per_out);
+    int fit = (IG_LDS_BUDGET_FLOATS - fixed - 4) / (per_in + per_out);
     if (fit > 64) fit = 64;
     int sb = 0;
     if (fit >= 1) {
@@ -362,7 +363,8 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
         if (p.pre && sb > cap) sb = cap;
     }
     p.SB = sb;
-    p.lds_in = sb * per_in; p.lds_w = wsum; p.lds_out = sb * g.N * g.OH * g.OW; p.lds_tab = tsum;
+    p.lds_in = (sb * per_in + 3) & ~3;  // keeps the weight image behind it 16-byte aligned
+    p.lds_w = wsum; p.lds_out = sb * g.N * g.OH * g.OW; p.lds_tab = tsum;
     p.lds_ptab = sb * g.OH * g.OW;
     p.total = p.lds_in + p.lds_w + p.lds_out + p.lds_tab + p.lds_ptab + coef;
     if (p.lds_in >= 65536 || p.lds_out >= 65536) p.SB = 0;  // the pixel table packs two 16-bit LDS offsets
@@ -504,9 +506,14 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     int wsum, tsum;
     a.ncls = fill_classes(a.g, a.cls, &wsum, &tsum);
     a.nchunks = (c.B + p.SB - 1) / p.SB;
-    for (int i = 0, poff = 0; i < a.ncls; ++i) {
-        a.cls[i].poff = poff;
-        poff += p.SB * a.cls[i].AH * a.cls[i].AW;
+    for (int i = 0, poff = 0; i < 4; ++i) {
+        if (i < a.ncls) {
+            a.cls[i].poff = poff;
+            poff += p.SB * a.cls[i].AH * a.cls[i].AW;
+        } else {  // unused classes start beyond everything (the kernel finds a lane's class by comparing starts)
+            memset(&a.cls[i], 0, sizeof(IgClass));
+            a.cls[i].poff = a.cls[i].woff = a.cls[i].toff = 0x7fffffff;
+        }
     }
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
@@ -514,13 +521,21 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
     const bool grad = a.in.mode >= TR_GRAD_BN;
+    // thin layers (few output channels, short K) run on the vector ALU inside the same kernel (igemm.h, ND)
+    int kmax = 0;
+    for (int i = 0; i < a.ncls; ++i) kmax = a.cls[i].Kc > kmax ? a.cls[i].Kc : kmax;
+    const int nd = (kmax <= 36 && a.g.N == 1) ? 1 : (kmax <= 36 && a.g.N <= 8) ? 8 : 0;
+#define IG_LAUNCH(NT, GR, ND) hipLaunchKernelGGL((igemm_gather_k<NT, 2, GR, ND>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a)
     if (a.g.Np > 16) {
-        if (grad) hipLaunchKernelGGL((igemm_gather_k<2, 2, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
-        else hipLaunchKernelGGL((igemm_gather_k<2, 2, false>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        if (grad) IG_LAUNCH(2, true, 0); else IG_LAUNCH(2, false, 0);
+    } else if (nd == 1) {
+        if (grad) IG_LAUNCH(1, true, 1); else IG_LAUNCH(1, false, 1);
+    } else if (nd == 8) {
+        if (grad) IG_LAUNCH(1, true, 8); else IG_LAUNCH(1, false, 8);
     } else {
-        if (grad) hipLaunchKernelGGL((igemm_gather_k<1, 2, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
-        else hipLaunchKernelGGL((igemm_gather_k<1, 2, false>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);
+        if (grad) IG_LAUNCH(1, true, 0); else IG_LAUNCH(1, false, 0);
     }
+#undef IG_LAUNCH
     VAE_LAUNCH_CHECK(what);
     if (a.slab != nullptr) c.last_blocks = a.nchunks;
     return VAE_OK;
