@@ -7,6 +7,7 @@ N>1 : configs[3]: same model, data-parallel, global batch 65536 split evenly, gr
 One step = eps draw + forward + ELBO + backward + Adam on a synthetic batch resident in HBM.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -49,9 +50,9 @@ def cpu_baseline(seconds=15.0, B=4096):
 
 
 def dominant_kernel_roofline(stepper, iters):
-    """Roofline of the dominant kernel, igemm_gather_k<1,2,false> (the forward implicit-GEMM gather of every
-    conv / transposed-conv layer with <= 16 output channels: 5 of the 6 conv layers of this model, the
-    largest share of the step in profiles/).  Its launches are timed live with HIP events on the launch
+    """Roofline of the dominant kernel, igemm_gather_k<1, 2, false, 0> (the forward implicit-GEMM gather on MFMA
+    tiles of the conv / transposed-conv layers with <= 16 output channels that are not thin enough for the
+    vector-ALU variant: conv2, convT1, convT2 of this model; the largest line of profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch
     stream (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
     achieved = algorithmic bytes per launch / average launch duration; algorithmic bytes of a launch =
     4 * B * (Cin*H*W + Cout*OH*OW) + 4 * weights + bias (input read once, output written once: DESIGN.md)."""
@@ -61,7 +62,8 @@ def dominant_kernel_roofline(stepper, iters):
     sel = []
     for i in range(prog.n_ops):
         op = prog.ops[i]
-        if op.kind in (L.OP_CONV, L.OP_CONVT) and (op.flags & L.F_FUSED) and op.d[3] <= 16:
+        if op.kind in (L.OP_CONV, L.OP_CONVT) and (op.flags & L.F_FUSED) and \
+                L.lib().vae_conv_forward_variant(ctypes.byref(op), stepper.B) == 100:
             cin, H, W, cout, OH, OW, KH, KW = [op.d[j] for j in range(8)]
             nbytes = 4 * (stepper.B * (cin * H * W + cout * OH * OW) + cin * cout * KH * KW + cout)
             sel.append((i, nbytes))
@@ -77,7 +79,7 @@ def dominant_kernel_roofline(stepper, iters):
     avg_bytes = sum(b for _, b in sel) / len(sel)
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if stepper.B == 4096 else None, "kernel": "igemm_gather_k<1, 2, false>",
+            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if stepper.B == 4096 else None, "kernel": "igemm_gather_k<1, 2, false, 0>",
             "launches_per_step": len(sel), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": avg_bytes,
             "per_launch_us": [t / iters * 1e3 for t in tot_ms],
             "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
@@ -92,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--model", default="mnist", choices=["mnist", "multiscale", "tcvae"],
+                    help="mnist = the contract workload (BASELINE configs[1]/[3]); multiscale / tcvae = configs[2] "
+                         "(dataGen-shaped windows, MSE ELBO) for the record in DESIGN.md")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -115,10 +120,24 @@ def main():
 
     B = args.batch or (4096 if world == 1 else 65536 // world)
     torch.manual_seed(0)
-    model = vae_amd.mnist_vae.VariationalAutoencoder(15).to(dev).train()
-    opt = vae_amd.optim.Adam(model.parameters(), lr=1e-3)
     g = torch.Generator(device=dev).manual_seed(rank)
-    x = torch.rand(B, 1, 28, 28, device=dev, generator=g)
+    if args.model == "mnist":
+        model = vae_amd.mnist_vae.VariationalAutoencoder(15)
+        x = torch.rand(B, 1, 28, 28, device=dev, generator=g)
+        workload = "MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam"
+    else:
+        if args.model == "multiscale":
+            model = vae_amd.multiscale_vae.vae(3, 60, 15)
+            workload = "multiscale_vae.vae(3, 60, 15) (12,255 params), MSE ELBO, Adam"
+        else:
+            model = vae_amd.VariationalAutoencoder(input_size=3, hidden_size=30, num_layers=3, latent_dims=15,
+                                                   v_encoder=vae_amd.Encoders.LongShort_TCVAE_Encoder,
+                                                   v_decoder=vae_amd.Decoders.LongShort_TCVAE_Decoder, L=60, slope=0.2,
+                                                   first_kernel=21)
+            workload = "TCVAE C=3 N=3 latent 15 L=60 first_kernel 21 (9,549 params), MSE ELBO, Adam"
+        x = 50 + 10 * torch.randn(B, 3, 60, device=dev, generator=g)  # dataGen-shaped windows (SURVEY 8d cfg 2)
+    model = model.to(dev).train()
+    opt = vae_amd.optim.Adam(model.parameters(), lr=1e-3)
     if world == 1:
         stepper = FusedTrainStep(model, opt, B, dev, use_graph=not args.no_graph)
     else:
@@ -150,7 +169,9 @@ def main():
     if not (loss == loss) or loss <= 0:
         raise SystemExit(f"loss is {loss}: the step is not training")
 
-    roof = dominant_kernel_roofline(stepper, args.roofline_iters) if rank == 0 else None  # (local launches only)
+    roof = None
+    if rank == 0 and args.model == "mnist":
+        roof = dominant_kernel_roofline(stepper, args.roofline_iters)  # (local launches only)
     barrier()
 
     if rank == 0:
@@ -161,16 +182,16 @@ def main():
             "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam, "
-                                    f"batch {B} per GPU, global batch {B * world}"),
+            "config": {"workload": f"{workload}, batch {B} per GPU, global batch {B * world}",
                        "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": ("single GPU, whole step as one hipGraph" if world == 1 else
                                        f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM (RCCL)")},
             "loss_per_sample": loss / B,
             "device_ms_per_step": dev_ms,
             # whole-step figure against the materialised-activation traffic model of SURVEY 8d (178 KB/sample)
-            "step_hbm_model_GBps": M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9,
         }
+        if args.model == "mnist":
+            line["step_hbm_model_GBps"] = M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

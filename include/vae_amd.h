@@ -137,6 +137,9 @@ int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world);
 /* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
  * the Python program builder; no GPU needed). */
 int vae_conv_fused_ok(const vae_op* op, int B);
+/* Which instance of the fused forward kernel the op gets at batch B (host-only; bench.py groups its launches
+ * by kernel name with it): 0 = not fused, else 100*NT + ND as in igemm_gather_k<NT, 2, false, ND>. */
+int vae_conv_forward_variant(const vae_op* op, int B);
 /* Floats of shared scratch (the op's r[6] slot) a FUSED CONV/CONVT op needs at batch B: the larger of
  * its BatchNorm statistic slabs and the per-workgroup weight-gradient partials.  0 if not fusable. */
 int64_t vae_conv_scratch_floats(const vae_op* op, int B);

@@ -145,6 +145,63 @@ def test_against_oracle_at_larger_batch(stem, family, kw, B):
     assert_grads_close({k: p.grad for k, p in m.named_parameters()}, ref["grads"], truth=truth64(family, sd, x, eps, **kw))
 
 
+def test_bench_workload_at_full_size():
+    """BASELINE configs[1] at its full size: the MNIST VAE, batch 4096, run exactly as bench.py runs it (the
+    fused step replayed as a hipGraph), against the CPU oracle on the same weights, batch and eps: loss,
+    every gradient, BatchNorm running statistics and the parameters after the Adam step."""
+    import vae_amd
+    from oracle import vae_oracle as O
+    from vae_amd.train import FusedTrainStep
+    B = 4096
+    g = load_golden("mnist_lat15")
+    sd = sub(g, "sd/")
+    gen = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 1, 28, 28, generator=gen)
+    eps = torch.randn(B, 15, generator=gen)
+    ref = O.loss_and_grads("mnist", sd, x, eps)
+    m = _build("mnist_lat15")
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
+    st = FusedTrainStep(m, opt, B, DEV, use_graph=True)
+    st.inject_eps = True
+    st.eps.copy_(eps)
+    loss = st.step(x.to(DEV))
+    close(loss, ref["loss"].reshape(1), atol=1.0)
+    close(st.output("x_rec"), ref["x_rec"])
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert_grads_close(grads, ref["grads"], truth=truth64("mnist", sd, x, eps))
+    new_sd = m.state_dict()
+    for k, v in ref["new_stats"].items():
+        close(new_sd[k], v, rtol=1e-4, atol=1e-5)
+    # one Adam step moves every parameter by at most lr; compare against the oracle's update
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    opt_ref = O.Adam(sd2, lr=1e-3)
+    O.train_step("mnist", sd2, opt_ref, x, eps)
+    assert_params_close({k: v.cpu() for k, v in new_sd.items()}, sd2, ref["grads"], steps=1, lr=1e-3)
+
+
+def test_batch_of_one():
+    """Edge of the batch dimension: a single sample, in eval mode (running statistics) and in train mode
+    (BatchNorm over the L > 1 positions of the one sample, as torch does), against golden / oracle."""
+    from oracle import vae_oracle as O
+    g = load_golden("tcvae_c3_n3_l60_fk21")
+    m = _build("tcvae_c3_n3_l60_fk21")
+    m.load_state_dict(sub(g, "sd3/"))
+    m.to(DEV).eval()
+    x1, e1 = g["x"][:1], g["eps_eval"][:1]
+    with torch.no_grad():
+        x_rec, mu, logvar = m(x1.to(DEV), eps=e1.to(DEV))
+    close(x_rec, g["eval/x_rec"][:1])
+    close(mu, g["eval/mu"][:1])
+    m.train()
+    want = O.tcvae_forward(sub(g, "sd3/"), x1, e1, num_layers=3, slope=0.2, training=True)
+    x_rec, mu, logvar = m(x1.to(DEV), eps=e1.to(DEV))
+    close(x_rec, want[0].detach())
+    close(mu, want[1].detach())
+    close(logvar, want[2].detach())
+
+
 def test_submodule_calls_and_reparam():
     """utils.py in the reference calls model.encoder / model.decoder / reparametrization_trick directly."""
     g = load_golden("tcvae_c3_n3_l60_fk21")

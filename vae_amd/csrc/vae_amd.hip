@@ -492,10 +492,31 @@ extern "C" int64_t vae_conv_scratch_floats(const vae_op* op, int B) {
     return slab > part ? slab : part;
 }
 
+extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
+static int gather_direct_nd(const IgGeom& g, const IgClass* cls, int ncls);
+extern "C" int vae_conv_forward_variant(const vae_op* op, int B) {
+    if (!vae_conv_fused_ok(op, B)) return 0;
+    const ConvGeom g = geom_of(*op);
+    const int T = op->kind == VAE_OP_CONVT;
+    const IgGeom f = make_geom(T, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, !T);
+    IgClass cls[4];
+    int wsum, tsum;
+    const int ncls = fill_classes(f, cls, &wsum, &tsum);
+    return (f.Np > 16 ? 200 : 100) + (f.Np > 16 ? 0 : gather_direct_nd(f, cls, ncls));
+}
+
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B) {
     if (op == nullptr || (op->kind != VAE_OP_CONV && op->kind != VAE_OP_CONVT) || B < 1) return 0;
     if (check_geom(*op) != VAE_OK) return 0;
     return conv_igemm_fits(*op, B);
+}
+
+// thin layers (few output channels, short K) run on the vector ALU inside the same kernel (igemm.h, ND):
+// returns the ND template argument, 0 = MFMA tiles
+static int gather_direct_nd(const IgGeom& g, const IgClass* cls, int ncls) {
+    int kmax = 0;
+    for (int i = 0; i < ncls; ++i) kmax = cls[i].Kc > kmax ? cls[i].Kc : kmax;
+    return (kmax <= 36 && g.N == 1) ? 1 : (kmax <= 36 && g.N <= 8) ? 8 : 0;
 }
 
 static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
@@ -521,10 +542,7 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
     const bool grad = a.in.mode >= TR_GRAD_BN;
-    // thin layers (few output channels, short K) run on the vector ALU inside the same kernel (igemm.h, ND)
-    int kmax = 0;
-    for (int i = 0; i < a.ncls; ++i) kmax = a.cls[i].Kc > kmax ? a.cls[i].Kc : kmax;
-    const int nd = (kmax <= 36 && a.g.N == 1) ? 1 : (kmax <= 36 && a.g.N <= 8) ? 8 : 0;
+    const int nd = gather_direct_nd(a.g, a.cls, a.ncls);
 #define IG_LAUNCH(NT, GR, ND) hipLaunchKernelGGL((igemm_gather_k<NT, 2, GR, ND>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a)
     if (a.g.Np > 16) {
         if (grad) IG_LAUNCH(2, true, 0); else IG_LAUNCH(2, false, 0);
