@@ -173,19 +173,37 @@ struct LinWgArgs {
     int act;
     float slope;
     int chunks_per_block;  // consecutive LW_BB-sample chunks handled by one workgroup
+    int gx, gy, gz;        // workgroups of this layer: batch slices x 32-row tiles x 64-column tiles
+    int first_block;       // of this layer in the flattened grid
 };
 
-__global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgArgs a) {
+// The weight gradients of ALL Linear layers of a backward pass in one launch (they only have to be done
+// before the optimiser; each is a few microseconds of latency-bound work, so running them side by side
+// costs about as much as running one).  Flat 1-D grid; a workgroup finds its layer from first_block.
+#define LIN_WG_MAX_LAYERS 8
+struct LinWgMulti {
+    LinWgArgs l[LIN_WG_MAX_LAYERS];
+    int n;
+};
+
+__global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+32)
     __shared__ float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < LIN_WG_MAX_LAYERS; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.l[i].first_block) layer = i;
+    const LinWgArgs& a = m.l[layer];
+    const int bid = blockIdx.x - a.first_block;
+    const int bx = bid % a.gx, by = (bid / a.gx) % a.gy, bz = bid / (a.gx * a.gy);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int n0 = blockIdx.y * 32, k0 = blockIdx.z * 64;
+    const int n0 = by * 32, k0 = bz * 64;
     const int nt = wid & 1, kt0 = (wid >> 1) * 2;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    const int c_first = blockIdx.x * a.chunks_per_block;
+    const int c_first = bx * a.chunks_per_block;
     for (int ch = c_first; ch < c_first + a.chunks_per_block; ++ch) {
         const int b0 = ch * LW_BB;
         if (b0 >= a.B) break;
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgArgs a) {
             Xs[(e >> 6) * LW_XS + (e & 63)] = vx[j];
         }
         __syncthreads();
-        if (a.db != nullptr && blockIdx.z == 0 && tid < 32) {
+        if (a.db != nullptr && bz == 0 && tid < 32) {
             float t = 0.f;
             for (int r = 0; r < LW_BB; ++r) t += Ys[r * LW_YS + tid];
             bsum += t;
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgArgs a) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x1, acc1, 0, 0, 0);
         }
     }
-    if (a.db != nullptr && blockIdx.z == 0 && tid < 32 && n0 + tid < a.N) atomicAdd(&a.db[n0 + tid], bsum);
+    if (a.db != nullptr && bz == 0 && tid < 32 && n0 + tid < a.N) atomicAdd(&a.db[n0 + tid], bsum);
     // D: row (n) = lk*4 + r, col (k) = li
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -7,7 +7,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-#include <stdlib.h>
 
 #include "chan.h"
 #include "common.h"
@@ -48,6 +47,7 @@ struct Ctx {
     int B;
     hipStream_t s;
     mutable int last_blocks;  // blocks that wrote the per-channel slab consumed by the next BN finalize
+    mutable LinWgMulti lin_wg;  // Linear weight gradients deferred to one launch at the end of backward
 };
 static inline int ref_space(int64_t r) { return (int)(r >> 56); }
 static inline int64_t ref_off(int64_t r) { return r & (((int64_t)1 << 56) - 1); }
@@ -858,6 +858,20 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     return VAE_OK;
 }
 
+static int flush_linear_wgrads(const Ctx& c) {
+    LinWgMulti& m = c.lin_wg;
+    if (m.n == 0) return VAE_OK;
+    int blocks = 0;
+    for (int i = 0; i < m.n; ++i) {
+        m.l[i].first_block = blocks;
+        blocks += m.l[i].gx * m.l[i].gy * m.l[i].gz;
+    }
+    hipLaunchKernelGGL(lin_wgrad_k, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    m.n = 0;
+    VAE_LAUNCH_CHECK("lin_wgrad_k");
+    return VAE_OK;
+}
+
 static int linear_check(const Ctx& c, const vae_op& op) {
     const int K = op.d[0], N = op.d[1];
     if (K < 1 || N < 1 || op.d[2] < K || op.d[3] < N) VAE_FAIL(VAE_EINVAL, "linear: bad K=%d N=%d ld=%d,%d", K, N, op.d[2], op.d[3]);
@@ -908,12 +922,17 @@ static int linear_backward(const Ctx& c, const vae_op& op) {
     wa.B = c.B; wa.N = N; wa.K = K; wa.act = op.act; wa.slope = op.f[0];
     const int tiles = ((N + 31) / 32) * ((K + 63) / 64);
     const int nch = (c.B + LW_BB - 1) / LW_BB;
-    int gx = (1024 + tiles - 1) / tiles;  // aim at ~1024 workgroups
+    int gx = (512 + tiles - 1) / tiles;  // ~512 workgroups per layer (all layers share one launch)
     if (gx > nch) gx = nch;
     wa.chunks_per_block = (nch + gx - 1) / gx;
     gx = (nch + wa.chunks_per_block - 1) / wa.chunks_per_block;
-    hipLaunchKernelGGL(lin_wgrad_k, dim3(gx, (N + 31) / 32, (K + 63) / 64), dim3(LIN_THREADS), 0, c.s, wa);
-    VAE_LAUNCH_CHECK("lin_wgrad_k");
+    wa.gx = gx; wa.gy = (N + 31) / 32; wa.gz = (K + 63) / 64;
+    // deferred: every Linear weight gradient of the pass goes into one launch (flush_linear_wgrads)
+    if (c.lin_wg.n == LIN_WG_MAX_LAYERS) {
+        rc = flush_linear_wgrads(c);
+        if (rc) return rc;
+    }
+    c.lin_wg.l[c.lin_wg.n++] = wa;
     // 2) dX[B][K] (=|+=) (dY*act') W
     if (dx != nullptr) {
         LinArgs b;
@@ -1040,6 +1059,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     if (B < 1 || B > (1 << 24)) VAE_FAIL(VAE_EINVAL, "batch %d out of range", B);
     c->bases = bases; c->sizes = sizes; c->n_bases = n_bases; c->B = B; c->s = (hipStream_t)stream;
     c->last_blocks = 0;
+    c->lin_wg.n = 0;
     return VAE_OK;
 }
 
@@ -1112,6 +1132,7 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
             default: vae_set_error("op %d: unknown kind %d", i, op.kind); rc = VAE_EINVAL;
         }
     }
+    if (rc == VAE_OK) rc = flush_linear_wgrads(c);
     return rc;
 }
 
