@@ -75,8 +75,9 @@ enum {
  *             act, f[0]=slope.  Weight layout: CONV [Cout][Cin][KH][KW], CONVT [Cin][Cout][KH][KW].
  *             VAE_F_FUSED adds: 7 in_bn (save block of the virtual BN that produced `in`, -1 none; then
  *             `in`/`din` name that BN's INPUT and its gradient), 8 out_bn (save block of the virtual BN
- *             that follows, -1 none), 9 running_mean of that BN (statistics pivot); r6 then also holds
- *             the per-block statistics slab (blocks*2*C floats).
+ *             that follows, -1 none), 9 running_mean of that BN (statistics pivot); r6 then holds the
+ *             per-chunk statistics slab (vae_conv_scratch_floats), 10 the op's own weight-gradient
+ *             partial region (vae_conv_wgrad_partial_floats; backward only).
  *  BN         r: 0 in, 1 out, 2 din, 3 dout, 4 gamma, 5 beta, 6 save (WORK, 8*C floats: mean, rstd,
  *                scale|sum_dy/n, shift|sum_dy_xhat/n, a, b, c, spare), 7 running_mean, 8 running_var
  *                (STATE), 9 partials / slab (WORK, shared scratch).  VAE_F_FUSED: 1 and 3 are -1.
@@ -140,9 +141,13 @@ int vae_conv_fused_ok(const vae_op* op, int B);
 /* Which instance of the fused forward kernel the op gets at batch B (host-only; bench.py groups its launches
  * by kernel name with it): 0 = not fused, else 100*NT + ND as in igemm_gather_k<NT, 2, false, ND>. */
 int vae_conv_forward_variant(const vae_op* op, int B);
-/* Floats of shared scratch (the op's r[6] slot) a FUSED CONV/CONVT op needs at batch B: the larger of
- * its BatchNorm statistic slabs and the per-workgroup weight-gradient partials.  0 if not fusable. */
+/* Floats of shared scratch (the op's r[6] slot) a FUSED CONV/CONVT op needs at batch B for its BatchNorm statistic
+ * slabs (+ the gathered data-parallel rows).  0 if not fusable. */
 int64_t vae_conv_scratch_floats(const vae_op* op, int B);
+/* Floats of the op's OWN weight-gradient partial region (r[10], WORK): one row per workgroup of the weight-gradient
+ * kernel.  The regions of different layers must not overlap: their reduction is deferred to one launch at the
+ * end of vae_run_backward. */
+int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B);
 
 /* Standalone criterion (autograd path).  Replaces train.py:39-48 / notebook :141-151.
  * out: 3 floats (loss, recon, kld).  partials: >= 2*VAE_ELBO_BLOCKS floats of scratch.

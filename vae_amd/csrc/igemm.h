@@ -659,15 +659,34 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
     }
 }
 
-// Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias.  One workgroup per 16
-// partial columns; its 16 slices stride over the partial rows, eight independent loads in flight each.
-__global__ __launch_bounds__(256) void wgrad_finalize_k(const float* __restrict__ part, int nrows, int NT, int T,
-                                                        int Sc, int NK, float* __restrict__ dw,
-                                                        float* __restrict__ dbias, int C) {
+// Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias, for EVERY conv layer of a backward
+// pass in one launch (each layer keeps its own partial region; the sums only have to exist before the
+// optimiser).  One workgroup per 16 partial columns of a layer; its 16 slices stride over the partial rows,
+// eight independent loads in flight each.  Flat grid: a workgroup finds its layer from first_block.
+#define WG_FIN_MAX_LAYERS 12
+struct WgFinLayer {
+    const float* part;
+    float* dw;
+    float* dbias;
+    int nrows, NT, T, Sc, NK, C;
+    int first_block;  // the layer owns T*16 + 4 workgroups from here
+};
+struct WgFinMulti {
+    WgFinLayer l[WG_FIN_MAX_LAYERS];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_finalize_k(WgFinMulti m) {
     __shared__ float red[16][17];
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < WG_FIN_MAX_LAYERS; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.l[i].first_block) layer = i;
+    const WgFinLayer& L = m.l[layer];
+    const float* __restrict__ part = L.part;
+    const int T = L.T, NT = L.NT, nrows = L.nrows;
     const int stride = T * 256 + 64;
     const int jj = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + jj;
+    const int j = ((int)blockIdx.x - L.first_block) * 16 + jj;
     float t[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) t[u] = 0.f;
@@ -685,10 +704,10 @@ __global__ __launch_bounds__(256) void wgrad_finalize_k(const float* __restrict_
     if (j < T * 256) {
         const int tile = j >> 8, r = (j >> 6) & 3, l = j & 63;
         const int mt = tile / NT, nt = tile - mt * NT;
-        const int m = mt * 16 + (l >> 4) * 4 + r, n = nt * 16 + (l & 15);
-        if (m < Sc && n < NK) dw[(int64_t)m * NK + n] += sum;
-    } else if (dbias != nullptr && j - T * 256 < C) {
-        dbias[j - T * 256] += sum;
+        const int mrow = mt * 16 + (l >> 4) * 4 + r, n = nt * 16 + (l & 15);
+        if (mrow < L.Sc && n < L.NK) L.dw[(int64_t)mrow * L.NK + n] += sum;
+    } else if (L.dbias != nullptr && j - T * 256 < L.C) {
+        L.dbias[j - T * 256] += sum;
     }
 }
 

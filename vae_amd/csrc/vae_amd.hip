@@ -48,6 +48,7 @@ struct Ctx {
     hipStream_t s;
     mutable int last_blocks;  // blocks that wrote the per-channel slab consumed by the next BN finalize
     mutable LinWgMulti lin_wg;  // Linear weight gradients deferred to one launch at the end of backward
+    mutable WgFinMulti wg_fin;  // conv weight-gradient partial reductions, likewise
 };
 static inline int ref_space(int64_t r) { return (int)(r >> 56); }
 static inline int64_t ref_off(int64_t r) { return r & (((int64_t)1 << 56) - 1); }
@@ -435,6 +436,20 @@ static int wgrad_grid(const WgPlan& wp, int nchunks) {
 static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
     return (int64_t)wgrad_grid(wp, (B + wp.SB - 1) / wp.SB) * (wp.MT * wp.NT * 256 + 64);
 }
+static int flush_wgrad_finalize(const Ctx& c) {
+    WgFinMulti& m = c.wg_fin;
+    if (m.n == 0) return VAE_OK;
+    int blocks = 0;
+    for (int i = 0; i < m.n; ++i) {
+        m.l[i].first_block = blocks;
+        blocks += m.l[i].T * 16 + 4;
+    }
+    hipLaunchKernelGGL(wgrad_finalize_k, dim3(blocks), dim3(256), 0, c.s, m);
+    m.n = 0;
+    VAE_LAUNCH_CHECK("wgrad_finalize_k");
+    return VAE_OK;
+}
+
 static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float* dw, float* db) {
     const int grid = wgrad_grid(wp, wa.nchunks);
     const size_t bytes = (size_t)wp.total * sizeof(float);
@@ -450,10 +465,14 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
         default: VAE_FAIL(VAE_EINVAL, "conv wgrad: no kernel for %dx%d accumulator tiles", wp.MT, wp.NT);
     }
     VAE_LAUNCH_CHECK("igemm_wgrad_k");
-    const int T = wp.MT * wp.NT;
-    hipLaunchKernelGGL(wgrad_finalize_k, dim3(T * 16 + 4), dim3(256), 0, c.s, wa.part, grid, wp.NT, T, wa.Sc,
-                       wa.Gc * wa.KH * wa.KW, dw, db, wa.bias_from_S ? wa.Sc : wa.Gc);
-    VAE_LAUNCH_CHECK("wgrad_finalize_k");
+    // the reduction of the partials is deferred: one launch for every conv layer of the pass (flush_wgrad_finalize)
+    if (c.wg_fin.n == WG_FIN_MAX_LAYERS) {
+        const int rc = flush_wgrad_finalize(c);
+        if (rc) return rc;
+    }
+    WgFinLayer& L = c.wg_fin.l[c.wg_fin.n++];
+    L.part = wa.part; L.dw = dw; L.dbias = db; L.nrows = grid; L.NT = wp.NT; L.T = wp.MT * wp.NT;
+    L.Sc = wa.Sc; L.NK = wa.Gc * wa.KH * wa.KW; L.C = wa.bias_from_S ? wa.Sc : wa.Gc;
     return VAE_OK;
 }
 
@@ -488,8 +507,17 @@ extern "C" int64_t vae_conv_scratch_floats(const vae_op* op, int B) {
     if (w.SB < 1) return 0;
     // BatchNorm slabs: <= one row per sample, plus one gathered row per data-parallel rank
     const int64_t slab = (int64_t)4 * (g.Cin > g.Cout ? g.Cin : g.Cout) * ((int64_t)B + VAE_MAX_WORLD);
-    const int64_t part = wgrad_part_floats(w, B);
-    return slab > part ? slab : part;
+    return slab;
+}
+
+extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
+    if (op == nullptr || (op->kind != VAE_OP_CONV && op->kind != VAE_OP_CONVT) || B < 1) return 0;
+    if (check_geom(*op) != VAE_OK) return 0;
+    const ConvGeom g = geom_of(*op);
+    const int T = op->kind == VAE_OP_CONVT;
+    const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
+                       : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+    return w.SB < 1 ? 0 : wgrad_part_floats(w, B);
 }
 
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
@@ -647,7 +675,7 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
         wa.Sc = g.Cin; wa.SH = g.H; wa.SW = g.W; wa.Gc = g.Cout; wa.GH = g.OH; wa.GW = g.OW;
     }
     if (wp.SB < 1) VAE_FAIL(VAE_EINVAL, "conv wgrad: layer does not fit the fused kernel");
-    wa.part = resolve(c, op.r[6], wgrad_part_floats(wp, c.B), "conv.wgrad_partials", &ok);
+    wa.part = resolve(c, op.r[10], wgrad_part_floats(wp, c.B), "conv.wgrad_partials", &ok);  // the layer's own region
     if (!ok) return VAE_EINVAL;
     wa.pre = wp.pre;
     wa.want_bias = db != nullptr; wa.B = c.B; wa.SB = wp.SB;
@@ -1060,6 +1088,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     c->bases = bases; c->sizes = sizes; c->n_bases = n_bases; c->B = B; c->s = (hipStream_t)stream;
     c->last_blocks = 0;
     c->lin_wg.n = 0;
+    c->wg_fin.n = 0;
     return VAE_OK;
 }
 
@@ -1132,6 +1161,7 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
             default: vae_set_error("op %d: unknown kind %d", i, op.kind); rc = VAE_EINVAL;
         }
     }
+    if (rc == VAE_OK) rc = flush_wgrad_finalize(c);
     if (rc == VAE_OK) rc = flush_linear_wgrads(c);
     return rc;
 }

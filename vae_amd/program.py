@@ -176,6 +176,8 @@ class ProgramBuilder:
             if op.kind in convs and lib.vae_conv_fused_ok(ctypes.byref(op), self.B):
                 op.flags |= L.F_FUSED
                 self.scratch_need = max(self.scratch_need, lib.vae_conv_scratch_floats(ctypes.byref(op), self.B))
+                if self.want_grads:  # the layer's own weight-gradient partials (reduced in one launch at the end)
+                    op.r[10] = self.fixed(lib.vae_conv_wgrad_partial_floats(ctypes.byref(op), self.B))
         out_refs = {buf.ref for buf, _ in self.outputs.values()}
         for bn in self.ops:
             if bn.kind != L.OP_BN or bn.r[1] in out_refs:
