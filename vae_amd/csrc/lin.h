@@ -203,23 +203,24 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
+    // Chunks are software-pipelined: the global loads of chunk i+1 are issued (into registers) before the
+    // MFMA loop of chunk i and only waited for when they are written to LDS one iteration later.
     const int c_first = bx * a.chunks_per_block;
-    for (int ch = c_first; ch < c_first + a.chunks_per_block; ++ch) {
+    const int c_end = min(c_first + a.chunks_per_block, (a.B + LW_BB - 1) / LW_BB);
+    const bool has_act = a.act != VAE_ACT_NONE;
+    float vy[8], vyy[8], vx[16];
+    auto load_chunk = [&](int ch) {  // 64 rows x 32 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
         const int b0 = ch * LW_BB;
-        if (b0 >= a.B) break;
-        __syncthreads();
-        // stage: 64 rows x 32 dY' columns and 64 rows x 64 X columns, zero beyond the edges
-        float vy[8], vx[16];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int e = tid + j * LIN_THREADS;  // 2048 = 64 x 32
             const int r = e >> 5, c = e & 31;
-            float v = 0.f;
+            vy[j] = 0.f;
+            vyy[j] = 0.f;
             if (b0 + r < a.B && n0 + c < a.N) {
-                v = a.dY[(int64_t)(b0 + r) * a.lddy + n0 + c];
-                if (a.act != VAE_ACT_NONE) v *= act_grad_from_out(a.Y[(int64_t)(b0 + r) * a.ldy + n0 + c], a.act, a.slope);
+                vy[j] = a.dY[(int64_t)(b0 + r) * a.lddy + n0 + c];
+                if (has_act) vyy[j] = a.Y[(int64_t)(b0 + r) * a.ldy + n0 + c];
             }
-            vy[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -227,10 +228,14 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             const int r = e >> 6, c = e & 63;
             vx[j] = (b0 + r < a.B && k0 + c < a.K) ? a.X[(int64_t)(b0 + r) * a.ldx + k0 + c] : 0.f;
         }
+    };
+    if (c_first < c_end) load_chunk(c_first);
+    for (int ch = c_first; ch < c_end; ++ch) {
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int e = tid + j * LIN_THREADS;
-            Ys[(e >> 5) * LW_YS + (e & 31)] = vy[j];
+            Ys[(e >> 5) * LW_YS + (e & 31)] = has_act ? vy[j] * act_grad_from_out(vyy[j], a.act, a.slope) : vy[j];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             Xs[(e >> 6) * LW_XS + (e & 63)] = vx[j];
         }
         __syncthreads();
+        if (ch + 1 < c_end) load_chunk(ch + 1);
         if (a.db != nullptr && bz == 0 && tid < 32) {
             float t = 0.f;
             for (int r = 0; r < LW_BB; ++r) t += Ys[r * LW_YS + tid];
