@@ -78,6 +78,7 @@ struct IgGeom {
 struct IgClass {
     int rh, rw, AH, AW, kh0, kw0, nkh, nkw, ntaps, Kc, KcPad, toff, woff;
     int poff;  // start of the class in the pixel table (filled at launch: SB * pixels of the earlier classes)
+    int w0, nw;  // the waves [w0, w0 + nw) of a workgroup that compute this class's MFMA tiles (filled at launch)
     FastDiv d_ntaps, d_nkw, d_AHW, d_AW;
 };
 
@@ -275,7 +276,6 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
 
         // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
-        int tile_base = 0;
         for (int cls = 0; cls < a.ncls; ++cls) {
             const IgClass& c = a.cls[cls];
             const int AHW = c.AH * c.AW;
@@ -327,13 +327,15 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const int ntile = (P + 15) >> 4;
             // TI tiles in flight per wave: their table -> gather -> MFMA -> store chains are independent,
             // which is what hides the LDS and MFMA latencies (the kernels are latency-, not issue-bound)
-            for (int t0 = (wid + IG_WAVES - (tile_base & (IG_WAVES - 1))) & (IG_WAVES - 1); t0 < ntile;
-                 t0 += IG_WAVES * TI) {
+            // the classes of a transposed gather run side by side: each owns waves [w0, w0 + nw) (host: in proportion
+            // to its tiles x K), instead of all eight waves walking the classes one after the other
+            if (wid < c.w0 || wid >= c.w0 + c.nw) continue;
+            for (int t0 = wid - c.w0; t0 < ntile; t0 += c.nw * TI) {
                 const float* lp[TI];
                 int outoff[TI];
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
-                    const int q = (t0 + i * IG_WAVES) * 16 + li;
+                    const int q = (t0 + i * c.nw) * 16 + li;
                     const bool valid = q < P;
                     const uint32_t pe = ptab[c.poff + (valid ? q : 0)];
                     lp[i] = lin + (pe & 0xffffu);
@@ -399,7 +401,6 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     }
                 }
             }
-            tile_base += ntile;
         }
         __syncthreads();
 

@@ -564,6 +564,24 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
             a.cls[i].poff = a.cls[i].woff = a.cls[i].toff = 0x7fffffff;
         }
     }
+    {   // waves per class in proportion to tiles x K: start with one each, hand the rest to the most loaded
+        int64_t work[4];
+        int nw[4], left = IG_WAVES - a.ncls;
+        for (int i = 0; i < a.ncls; ++i) {
+            work[i] = (int64_t)((p.SB * a.cls[i].AH * a.cls[i].AW + 15) / 16) * (a.cls[i].KcPad > 0 ? a.cls[i].KcPad : 1);
+            nw[i] = 1;
+        }
+        for (; left > 0; --left) {
+            int best = 0;
+            for (int i = 1; i < a.ncls; ++i)
+                if (work[i] * nw[best] > work[best] * nw[i]) best = i;
+            ++nw[best];
+        }
+        for (int i = 0, w0 = 0; i < a.ncls; ++i) {
+            a.cls[i].w0 = w0; a.cls[i].nw = nw[i];
+            w0 += nw[i];
+        }
+    }
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
     const int g_max = IG_MAX_GRID;
