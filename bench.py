@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--roofline-iters", type=int, default=20)
-    ap.add_argument("--model", default="mnist", choices=["mnist", "multiscale", "tcvae"],
+    ap.add_argument("--model", default="mnist", choices=["mnist", "wide", "multiscale", "tcvae"],
                     help="mnist = the contract workload (BASELINE configs[1]/[3]); multiscale / tcvae = configs[2] "
                          "(dataGen-shaped windows, MSE ELBO) for the record in DESIGN.md")
     args = ap.parse_args()
@@ -121,15 +121,19 @@ def main():
     B = args.batch or (4096 if world == 1 else 65536 // world)
     torch.manual_seed(0)
     g = torch.Generator(device=dev).manual_seed(rank)
-    if args.model == "mnist":
-        model = vae_amd.mnist_vae.VariationalAutoencoder(15)
+    if args.model in ("mnist", "wide"):
+        if args.model == "mnist":
+            model = vae_amd.mnist_vae.VariationalAutoencoder(15)
+            workload = "MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam"
+        else:  # BASELINE configs[4]; hidden width kept at 100 (SURVEY 8d asks to state the choice)
+            model = vae_amd.mnist_vae.VariationalAutoencoder(256, channels=(32, 64, 128), hidden=100)
+            workload = "widened MNIST Conv2d VAE (channels 32/64/128, latent 256, hidden 100), BCE ELBO, Adam"
         x = torch.rand(B, 1, 28, 28, device=dev, generator=g)
-        workload = "MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam"
     else:
         if args.model == "multiscale":
             model = vae_amd.multiscale_vae.vae(3, 60, 15)
             workload = "multiscale_vae.vae(3, 60, 15) (12,255 params), MSE ELBO, Adam"
-        else:
+        elif args.model == "tcvae":
             model = vae_amd.VariationalAutoencoder(input_size=3, hidden_size=30, num_layers=3, latent_dims=15,
                                                    v_encoder=vae_amd.Encoders.LongShort_TCVAE_Encoder,
                                                    v_decoder=vae_amd.Decoders.LongShort_TCVAE_Decoder, L=60, slope=0.2,

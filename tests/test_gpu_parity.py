@@ -181,6 +181,29 @@ def test_bench_workload_at_full_size():
     assert_params_close({k: v.cpu() for k, v in new_sd.items()}, sd2, ref["grads"], steps=1, lr=1e-3)
 
 
+def test_widened_model_vs_oracle():
+    """BASELINE configs[4]: the MNIST VAE with 4x conv channels (32/64/128) and latent 256.  Layers beyond the
+    fused kernels' budgets fall back to the direct HIP kernels; results must not depend on which path ran."""
+    import vae_amd
+    from oracle import vae_oracle as O
+    B = 96
+    torch.manual_seed(5)
+    m = vae_amd.mnist_vae.VariationalAutoencoder(256, channels=(32, 64, 128), hidden=100)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand(B, 1, 28, 28, generator=gen)
+    eps = torch.randn(B, 256, generator=gen)
+    ref = O.loss_and_grads("mnist", sd, x, eps)
+    m.to(DEV).train()
+    x_rec, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+    close(x_rec, ref["x_rec"])
+    close(mu, ref["mu"])
+    loss = _crit("mnist")(x_rec, x.to(DEV), mu, logvar)
+    close(loss, ref["loss"], atol=1e-1)
+    loss.backward()
+    assert_grads_close({k: p.grad for k, p in m.named_parameters()}, ref["grads"], truth=truth64("mnist", sd, x, eps))
+
+
 def test_batch_of_one():
     """Edge of the batch dimension: a single sample, in eval mode (running statistics) and in train mode
     (BatchNorm over the L > 1 positions of the one sample, as torch does), against golden / oracle."""
