@@ -27,6 +27,14 @@ GEOMS = [
     (7, 5, 4, 9, 4, 3, 2, 1, True, 0, 12),
     (3, 8, 8, 5, 3, 3, 1, 1, True, 0, 17),          # transposed, stride 1
     (2, 10, 10, 2, 5, 5, 2, 2, True, 1, 9),
+    # wide layers: the K-loop MFMA kernels of wide.h (forward, input gradient and weight gradient)
+    (32, 14, 14, 64, 3, 3, 2, 1, False, 0, 40),
+    (64, 7, 7, 128, 3, 3, 2, 0, False, 0, 21),
+    (128, 3, 3, 64, 3, 3, 2, 0, True, 0, 33),
+    (64, 7, 7, 32, 3, 3, 2, 1, True, 1, 18),
+    (20, 1, 30, 70, 1, 5, 1, 2, False, 0, 11),     # two channel tiles, ragged everything
+    (40, 6, 5, 24, 3, 4, 2, 1, True, 1, 14),
+    (48, 4, 4, 40, 2, 2, 2, 0, True, 0, 7),        # one tap per parity class
 ]
 
 

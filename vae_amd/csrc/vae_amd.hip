@@ -14,6 +14,7 @@
 #include "elem.h"
 #include "igemm.h"
 #include "lin.h"
+#include "wide.h"
 
 static thread_local char g_err[512] = "";
 void vae_set_error(const char* fmt, ...) {
@@ -96,6 +97,16 @@ static inline void chunking(int B, int64_t per_sample, int* bchunk, int* nchunks
     *nchunks = (int)ceil_div64(B, *bchunk);
 }
 
+// layers at least this wide (output rows x reduction length) take the K-loop MFMA kernels of wide.h
+#define WIDE_MIN_N 16
+#define WIDE_MIN_K 32
+static FastDiv mk_fdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.mul = d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0;
+    return f;
+}
+
 // ---- conv launches ---------------------------------------------------------------------------
 static ConvGeom geom_of(const vae_op& op) {
     ConvGeom g;
@@ -126,6 +137,14 @@ static int launch_conv_gather(const Ctx& c, const float* x, const float* w, cons
                               const ConvGeom& g, int act, float slope, int accumulate) {
     const int64_t npix = (int64_t)c.B * g.OH * g.OW;
     const int gx = (int)ceil_div64(npix, 256);
+    const int64_t K = (int64_t)g.Cin * g.KH * g.KW;
+    if (g.Cout >= WIDE_MIN_N && K >= WIDE_MIN_K && K < (1 << 20) && ceil_div64(npix, 64) < (1ll << 31)) {
+        dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64);
+        hipLaunchKernelGGL(wide_gather_k<false>, grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                           accumulate);
+        VAE_LAUNCH_CHECK("wide_gather_k");
+        return VAE_OK;
+    }
     if (g.Cout > 4) {
         dim3 grid(gx, (g.Cout + 7) / 8);
         hipLaunchKernelGGL(conv_gather_k<8>, grid, dim3(256), 0, c.s, x, w, bias, y, c.B, g, act, slope, accumulate);
@@ -142,6 +161,14 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
     const int AH = (g.OH + g.sh - 1) / g.sh, AW = (g.OW + g.sw - 1) / g.sw;
     const int64_t npix = (int64_t)c.B * AH * AW;
     const int gx = (int)ceil_div64(npix, 256);
+    const int64_t K = (int64_t)g.Cin * ((g.KH + g.sh - 1) / g.sh) * ((g.KW + g.sw - 1) / g.sw);  // largest class
+    if (g.Cout >= WIDE_MIN_N && K >= WIDE_MIN_K && K < (1 << 20) && ceil_div64(npix, 64) < (1ll << 31)) {
+        dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64, g.sh * g.sw);
+        hipLaunchKernelGGL(wide_gather_k<true>, grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                           accumulate);
+        VAE_LAUNCH_CHECK("wide_gather_k");
+        return VAE_OK;
+    }
     if (g.Cout > 4) {
         dim3 grid(gx, (g.Cout + 7) / 8, g.sh * g.sw);
         hipLaunchKernelGGL(convT_gather_k<8>, grid, dim3(256), 0, c.s, x, w, bias, y, c.B, g, act, slope, accumulate);
@@ -156,6 +183,24 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
 static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw, int A, int SH, int SW, int C,
                         int GH, int GW, int KH, int KW, int sh, int sw, int ph, int pw) {
     const int64_t R = (int64_t)c.B * SH * SW;
+    const int64_t NK = (int64_t)C * KH * KW;
+    if (A >= WIDE_MIN_N && NK >= WIDE_MIN_K && R < (1ll << 31) && R * SH * SW < (1ll << 32) && NK < (1 << 24)) {
+        WideWgArgs a;
+        a.S = S; a.G = G; a.dw = dw;
+        a.B = c.B; a.A = A; a.SH = SH; a.SW = SW; a.C = C; a.GH = GH; a.GW = GW; a.KH = KH; a.KW = KW;
+        a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
+        const int gy = (A + 63) / 64, gz = (int)ceil_div64(NK, 64);
+        int64_t chunks = ceil_div64(2048, (int64_t)gy * gz);       // ~8 workgroups per CU over the whole grid
+        int64_t chunk = ceil_div64(ceil_div64(R, chunks), 16) * 16;
+        if (chunk < 256) chunk = 256;                               // >= 16 K steps before paying the atomics
+        a.R = R; a.chunk = chunk;
+        a.d_SHW = mk_fdiv((uint32_t)(SH * SW)); a.d_SW = mk_fdiv((uint32_t)SW);
+        a.d_KK = mk_fdiv((uint32_t)(KH * KW)); a.d_KW = mk_fdiv((uint32_t)KW);
+        dim3 grid((unsigned)ceil_div64(R, chunk), gy, gz);
+        hipLaunchKernelGGL(wide_wgrad_k, grid, dim3(WD_THREADS), 0, c.s, a);
+        VAE_LAUNCH_CHECK("wide_wgrad_k");
+        return VAE_OK;
+    }
     const int AT = 4, TG = (KH * KW <= 9) ? 9 : 16;
     const int tiles = ((A + AT - 1) / AT) * C;
     const int zg = (KH * KW + TG - 1) / TG;
@@ -252,12 +297,6 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
 #define IG_SB_TARGET 1024   // chunk = ceil(B / target) samples (bounded by the LDS budget and the prefetch registers)
 #define IG_WG_SB_TARGET 1024
 
-static FastDiv mk_fdiv(uint32_t d) {
-    FastDiv f;
-    f.d = d;
-    f.mul = d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0;
-    return f;
-}
 
 // Geometry of a gather that reads (Cin,H,W) and produces (N,OH,OW).  transposed: ConvT forward /
 // Conv dgrad; else Conv forward / ConvT dgrad.  wform_conv: weight element (ci,n) at

@@ -1,0 +1,262 @@
+// wide.h - convolution layers too wide for the LDS-resident kernels of igemm.h (their [k][n] weight image or
+// their accumulator tiles do not fit): classic implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32) with a K loop.
+//
+// A workgroup (256 threads, 4 waves) owns a 64 x 64 output tile; every K step stages 16 k-columns of both
+// operands in LDS ([row][17] layout: conflict-free for the global->LDS fill and for the MFMA operand reads),
+// double-buffered, the next step's global loads in flight during the MFMAs of the current one.
+//
+//   wide_gather_k<TR> : y[b,n,oh,ow] = act(bias[n] + sum_k x(gathered) * w)   (= conv_gather_k / convT_gather_k
+//                       of conv.h: Conv forward + ConvT input gradient; TR: ConvT forward + Conv input gradient).
+//                       GEMM: D[channel][pixel], K = (ci, tap); transposed gathers run per output-parity class.
+//   wide_wgrad_k      : dw[a][c][kh][kw] += sum_{b,oh,ow} S[b,a,oh,ow] * G[b,c,oh*sh-ph+kh,ow*sw-pw+kw]
+//                       (= conv_wgrad_k).  GEMM: D[a][(c,tap)], K = pixels, split over grid.x, float atomics into
+//                       the zeroed dw (tens of adds per element: the matrices are large here).
+#pragma once
+#include "common.h"
+#include "conv.h"
+#include "igemm.h"  // f32x4, FastDiv
+
+#define WD_THREADS 256
+#define WD_ST 17  // LDS row stride (floats)
+
+// exact n / d for 0 <= n < 2^20 and small d through the float reciprocal (inv = 1.f / d)
+__device__ __forceinline__ int wd_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+__device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, int arow0, int brow0, int li, int lk,
+                                             f32x4 (&acc)[2][2]) {
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 4) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            av[t] = As[(arow0 + t * 16 + li) * WD_ST + k4 + lk];
+            bv[t] = Bs[(brow0 + t * 16 + li) * WD_ST + k4 + lk];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+    }
+}
+
+template <bool TR>
+__global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                            ConvGeom g, int act, float slope, int accumulate) {
+    __shared__ float Ws[2][64 * WD_ST];  // [channel][k]
+    __shared__ float Xs[2][64 * WD_ST];  // [pixel][k]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // output-parity class (transposed) / the whole output (plain)
+    int rh = 0, rw = 0, AH = g.OH, AW = g.OW, kh0 = 0, kw0 = 0, nkh = g.KH, nkw = g.KW, dh0 = 0, dw0 = 0;
+    if (TR) {
+        rh = blockIdx.z / g.sw; rw = blockIdx.z % g.sw;
+        AH = (g.OH - rh + g.sh - 1) / g.sh; AW = (g.OW - rw + g.sw - 1) / g.sw;
+        if (AH <= 0 || AW <= 0) return;
+        kh0 = (rh + g.ph) % g.sh; kw0 = (rw + g.pw) % g.sw;
+        nkh = kh0 < g.KH ? (g.KH - kh0 + g.sh - 1) / g.sh : 0;
+        nkw = kw0 < g.KW ? (g.KW - kw0 + g.sw - 1) / g.sw : 0;
+        dh0 = (rh + g.ph - kh0) / g.sh; dw0 = (rw + g.pw - kw0) / g.sw;  // exact: multiples of the stride
+    }
+    const int ntaps = nkh * nkw, K = g.Cin * ntaps, KK = g.KH * g.KW;
+    const float inv_ntaps = ntaps > 0 ? 1.f / (float)ntaps : 0.f, inv_nkw = nkw > 0 ? 1.f / (float)nkw : 0.f;
+    const int64_t npix = (int64_t)B * AH * AW;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    if (p0 >= npix) return;
+
+    // this thread's pixel for the operand fill (64 pixels x 4 k-columns per thread and step)
+    const int64_t p = p0 + (tid & 63);
+    const bool pvalid = p < npix;
+    int aw = 0, ah = 0;
+    int64_t b = 0;
+    if (pvalid) {
+        aw = (int)(p % AW);
+        const int64_t t = p / AW;
+        ah = (int)(t % AH);
+        b = t / AH;
+    }
+    const float* xb = x + b * (int64_t)g.Cin * g.H * g.W;
+    const int ihb = TR ? ah + dh0 : ah * g.sh - g.ph, iwb = TR ? aw + dw0 : aw * g.sw - g.pw;
+
+    float xr[4], wr[4];
+    auto load_step = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            {   // activations: pixel = tid & 63, k column = (tid >> 6) + 4j
+                const int k = k0 + (tid >> 6) + 4 * j;
+                float v = 0.f;
+                if (pvalid && k < K) {
+                    const int ci = wd_div(k, inv_ntaps), ti = k - ci * ntaps;
+                    const int i_h = wd_div(ti, inv_nkw), i_w = ti - i_h * nkw;
+                    const int ih = TR ? ihb - i_h : ihb + i_h, iw = TR ? iwb - i_w : iwb + i_w;
+                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = xb[((int64_t)ci * g.H + ih) * g.W + iw];
+                }
+                xr[j] = v;
+            }
+            {   // weights: plain layout [n][ci][kh][kw] has k contiguous (k fastest over the lanes);
+                // transposed layout [ci][n][kh][kw] is walked with n fastest
+                const int kk = TR ? (tid >> 6) + 4 * j : (tid & 15);
+                const int n = TR ? (tid & 63) : (tid >> 4) + 16 * j;
+                const int k = k0 + kk;
+                float v = 0.f;
+                if (n0 + n < g.Cout && k < K) {
+                    const int ci = wd_div(k, inv_ntaps), ti = k - ci * ntaps;
+                    const int i_h = wd_div(ti, inv_nkw), i_w = ti - i_h * nkw;
+                    const int kh = TR ? kh0 + i_h * g.sh : i_h, kw = TR ? kw0 + i_w * g.sw : i_w;
+                    v = TR ? w[((int64_t)ci * g.Cout + n0 + n) * KK + kh * g.KW + kw]
+                           : w[((int64_t)(n0 + n) * g.Cin + ci) * KK + kh * g.KW + kw];
+                }
+                wr[j] = v;
+            }
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Xs[buf][(tid & 63) * WD_ST + (tid >> 6) + 4 * j] = xr[j];
+            const int kk = TR ? (tid >> 6) + 4 * j : (tid & 15);
+            const int n = TR ? (tid & 63) : (tid >> 4) + 16 * j;
+            Ws[buf][n * WD_ST + kk] = wr[j];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ch_half = wid >> 1, px_half = wid & 1;
+    const int nsteps = (K + 15) / 16;
+    if (nsteps > 0) {
+        load_step(0);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) load_step((s + 1) * 16);  // in flight during the MFMAs below
+        wd_mfma_step(Ws[s & 1], Xs[s & 1], ch_half * 32, px_half * 32, li, lk, acc);
+        if (s + 1 < nsteps) store_step((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // D: row (channel) = lk*4 + r, col (pixel) = li
+    const int64_t ohw = (int64_t)g.OH * g.OW;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t q = p0 + px_half * 32 + u * 16 + li;
+        if (q >= npix) continue;
+        const int qaw = (int)(q % AW);
+        const int64_t t = q / AW;
+        const int qah = (int)(t % AH);
+        const int64_t qb = t / AH;
+        const int oh = TR ? qah * g.sh + rh : qah, ow = TR ? qaw * g.sw + rw : qaw;
+        float* yp = y + qb * g.Cout * ohw + (int64_t)oh * g.OW + ow;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + ch_half * 32 + t2 * 16 + lk * 4 + r;
+                if (n < g.Cout) {
+                    float v = act_apply(acc[t2][u][r] + (bias != nullptr ? bias[n] : 0.f), act, slope);
+                    if (accumulate) v += yp[n * ohw];
+                    yp[n * ohw] = v;
+                }
+            }
+    }
+}
+
+struct WideWgArgs {
+    const float* S;  // [B][A][SH][SW]
+    const float* G;  // [B][C][GH][GW]
+    float* dw;       // [A][C][KH][KW]
+    int B, A, SH, SW, C, GH, GW, KH, KW, sh, sw, ph, pw;
+    int64_t R, chunk;       // reduction length B*SH*SW and the slice of it one grid.x index takes
+    FastDiv d_SHW, d_SW, d_KK, d_KW;
+};
+
+__global__ __launch_bounds__(WD_THREADS) void wide_wgrad_k(WideWgArgs a) {
+    __shared__ float Ss[2][64 * WD_ST];  // [a][pixel]
+    __shared__ float Gs[2][64 * WD_ST];  // [(c,tap)][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int SHW = a.SH * a.SW, KK = a.KH * a.KW, NK = a.C * KK;
+    const int a0 = blockIdx.y * 64, n0 = blockIdx.z * 64;
+    const int64_t r_begin = (int64_t)blockIdx.x * a.chunk;
+    const int64_t r_end = r_begin + a.chunk < a.R ? r_begin + a.chunk : a.R;
+    if (r_begin >= r_end) return;
+
+    // per-thread constants of the G fill: (c, kh, kw) of its four columns
+    int gc[4], gkh[4], gkw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (tid >> 4) + 16 * j;
+        gc[j] = -1;
+        gkh[j] = gkw[j] = 0;
+        if (n < NK) {
+            gc[j] = fdiv((uint32_t)n, a.d_KK);
+            const int tap = n - gc[j] * KK;
+            gkh[j] = fdiv((uint32_t)tap, a.d_KW);
+            gkw[j] = tap - gkh[j] * a.KW;
+        }
+    }
+    float sr[4], gr[4];
+    auto load_step = [&](int64_t r0) {
+        const int64_t r = r0 + (tid & 15);  // this thread's pixel in the step (16 pixels, pixel fastest over lanes)
+        const bool rv = r < r_end;
+        int b = 0, oh = 0, ow = 0, pix = 0;
+        if (rv) {
+            b = fdiv((uint32_t)r, a.d_SHW);
+            pix = (int)r - b * SHW;
+            oh = fdiv((uint32_t)pix, a.d_SW);
+            ow = pix - oh * a.SW;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int aa = a0 + (tid >> 4) + 16 * j;
+            sr[j] = (rv && aa < a.A) ? a.S[((int64_t)b * a.A + aa) * SHW + pix] : 0.f;
+            float v = 0.f;
+            if (rv && gc[j] >= 0) {
+                const int gh = oh * a.sh - a.ph + gkh[j], gw = ow * a.sw - a.pw + gkw[j];
+                if (gh >= 0 && gh < a.GH && gw >= 0 && gw < a.GW) v = a.G[(((int64_t)b * a.C + gc[j]) * a.GH + gh) * a.GW + gw];
+            }
+            gr[j] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Ss[buf][((tid >> 4) + 16 * j) * WD_ST + (tid & 15)] = sr[j];
+            Gs[buf][((tid >> 4) + 16 * j) * WD_ST + (tid & 15)] = gr[j];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_half = wid >> 1, n_half = wid & 1;
+    const int nsteps = (int)((r_end - r_begin + 15) / 16);
+    load_step(r_begin);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) load_step(r_begin + (int64_t)(s + 1) * 16);
+        wd_mfma_step(Ss[s & 1], Gs[s & 1], a_half * 32, n_half * 32, li, lk, acc);
+        if (s + 1 < nsteps) store_step((s + 1) & 1);
+        __syncthreads();
+    }
+    // D: row (a) = lk*4 + r, col ((c,tap)) = li
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int aa = a0 + a_half * 32 + t * 16 + lk * 4 + r;
+                const int n = n0 + n_half * 32 + u * 16 + li;
+                if (aa < a.A && n < NK) atomicAdd(&a.dw[(int64_t)aa * NK + n], acc[t][u][r]);
+            }
+}
