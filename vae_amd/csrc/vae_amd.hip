@@ -100,6 +100,7 @@ static inline void chunking(int B, int64_t per_sample, int* bchunk, int* nchunks
 // layers at least this wide (output rows x reduction length) take the K-loop MFMA kernels of wide.h
 #define WIDE_MIN_N 16
 #define WIDE_MIN_K 32
+#define WIDE_WG_BLOCKS 768  // split of the weight gradient's reduction: more workgroups = more float atomics per dw line
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
     f.d = d;
@@ -132,16 +133,28 @@ static int check_geom(const vae_op& op) {
     return VAE_OK;
 }
 
+// K = longest reduction of the launch (Cin x taps; per parity class for the transposed gather)
+static bool wide_gather_ok(const ConvGeom& g, int64_t K, int64_t npix) {
+    return g.Cout >= WIDE_MIN_N && K >= WIDE_MIN_K && K <= WD_KTAB_MAX && ceil_div64(npix, 64) < (1ll << 31) &&
+           g.H < 16384 && g.W < 16384 && g.OH < 16384 && g.OW < 16384 && g.KH < 256 && g.KW < 256 &&
+           (int64_t)g.Cin * g.H * g.W < (1ll << 30);
+}
 // y = conv(x): geometry in "conv orientation" (Cin,H,W) -> (Cout,OH,OW)
 static int launch_conv_gather(const Ctx& c, const float* x, const float* w, const float* bias, float* y,
                               const ConvGeom& g, int act, float slope, int accumulate) {
     const int64_t npix = (int64_t)c.B * g.OH * g.OW;
     const int gx = (int)ceil_div64(npix, 256);
     const int64_t K = (int64_t)g.Cin * g.KH * g.KW;
-    if (g.Cout >= WIDE_MIN_N && K >= WIDE_MIN_K && K < (1 << 20) && ceil_div64(npix, 64) < (1ll << 31)) {
-        dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64);
-        hipLaunchKernelGGL(wide_gather_k<false>, grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                           accumulate);
+    if (wide_gather_ok(g, K, npix)) {
+        if (g.Cout <= 32) {
+            dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32);
+            hipLaunchKernelGGL((wide_gather_k<false, 1>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                               accumulate);
+        } else {
+            dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64);
+            hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                               accumulate);
+        }
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
     }
@@ -162,10 +175,16 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
     const int64_t npix = (int64_t)c.B * AH * AW;
     const int gx = (int)ceil_div64(npix, 256);
     const int64_t K = (int64_t)g.Cin * ((g.KH + g.sh - 1) / g.sh) * ((g.KW + g.sw - 1) / g.sw);  // largest class
-    if (g.Cout >= WIDE_MIN_N && K >= WIDE_MIN_K && K < (1 << 20) && ceil_div64(npix, 64) < (1ll << 31)) {
-        dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64, g.sh * g.sw);
-        hipLaunchKernelGGL(wide_gather_k<true>, grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                           accumulate);
+    if (wide_gather_ok(g, K, npix)) {
+        if (g.Cout <= 32) {
+            dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32, g.sh * g.sw);
+            hipLaunchKernelGGL((wide_gather_k<true, 1>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                               accumulate);
+        } else {
+            dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64, g.sh * g.sw);
+            hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
+                               accumulate);
+        }
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
     }
@@ -190,7 +209,7 @@ static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw,
         a.B = c.B; a.A = A; a.SH = SH; a.SW = SW; a.C = C; a.GH = GH; a.GW = GW; a.KH = KH; a.KW = KW;
         a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
         const int gy = (A + 63) / 64, gz = (int)ceil_div64(NK, 64);
-        int64_t chunks = ceil_div64(2048, (int64_t)gy * gz);       // ~8 workgroups per CU over the whole grid
+        int64_t chunks = ceil_div64(WIDE_WG_BLOCKS, (int64_t)gy * gz);
         int64_t chunk = ceil_div64(ceil_div64(R, chunks), 16) * 16;
         if (chunk < 256) chunk = 256;                               // >= 16 K steps before paying the atomics
         a.R = R; a.chunk = chunk;

@@ -39,12 +39,22 @@ __device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, i
     }
 }
 
-template <bool TR>
+#define WD_KTAB_MAX 2304  // longest reduction (Cin x taps) the gather's LDS tap table holds
+
+// CW = channel waves: the tile is 32*CW channels x 64 pixels (CW = 1 keeps layers with <= 32 output channels from
+// computing a half-empty 64-channel tile).  Wave layout: CW x (4/CW) waves, each 2 channel tiles x CW pixel tiles.
+template <bool TR, int CW>
 __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
                                                             ConvGeom g, int act, float slope, int accumulate) {
-    __shared__ float Ws[2][64 * WD_ST];  // [channel][k]
-    __shared__ float Xs[2][64 * WD_ST];  // [pixel][k]
+    constexpr int NCH = 32 * CW;  // channels per tile
+    constexpr int WJ = 2 * CW;    // weight elements a thread fills per K step
+    constexpr int PXT = CW;       // 16-pixel tiles per wave
+    __shared__ float Ws[2][NCH * WD_ST];  // [channel][k]
+    __shared__ float Xs[2][64 * WD_ST];   // [pixel][k]
+    __shared__ int kt_delta[WD_KTAB_MAX]; // k -> offset of its tap from the pixel's base address
+    __shared__ int kt_hw[WD_KTAB_MAX];    // k -> (i_h << 16) | i_w, tap position for the bounds check
+    __shared__ int kt_w[TR ? WD_KTAB_MAX : 1];  // k -> weight offset without the output channel (transposed layout)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
 
@@ -59,12 +69,27 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
         nkw = kw0 < g.KW ? (g.KW - kw0 + g.sw - 1) / g.sw : 0;
         dh0 = (rh + g.ph - kh0) / g.sh; dw0 = (rw + g.pw - kw0) / g.sw;  // exact: multiples of the stride
     }
-    const int ntaps = nkh * nkw, K = g.Cin * ntaps, KK = g.KH * g.KW;
-    const float inv_ntaps = ntaps > 0 ? 1.f / (float)ntaps : 0.f, inv_nkw = nkw > 0 ? 1.f / (float)nkw : 0.f;
+    const int ntaps = nkh * nkw, K = g.Cin * ntaps, KK = g.KH * g.KW, HW = g.H * g.W;
+    const int nsteps = (K + 15) / 16;
     const int64_t npix = (int64_t)B * AH * AW;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
-    const int n0 = blockIdx.y * 64;
+    const int n0 = blockIdx.y * NCH;
     if (p0 >= npix) return;
+
+    // tap table; the padding entries up to the last K step fail every bounds check
+    for (int k = tid; k < nsteps * 16; k += WD_THREADS) {
+        int delta = 0, hw = 0x7fff0000, wo = 0;
+        if (k < K) {
+            const int ci = k / ntaps, ti = k - ci * ntaps;
+            const int i_h = ti / nkw, i_w = ti - i_h * nkw;
+            delta = TR ? ci * HW - i_h * g.W - i_w : ci * HW + i_h * g.W + i_w;
+            hw = (i_h << 16) | i_w;
+            if (TR) wo = ci * g.Cout * KK + (kh0 + i_h * g.sh) * g.KW + kw0 + i_w * g.sw;
+        }
+        kt_delta[k] = delta;
+        kt_hw[k] = hw;
+        if (TR) kt_w[k] = wo;
+    }
 
     // this thread's pixel for the operand fill (64 pixels x 4 k-columns per thread and step)
     const int64_t p = p0 + (tid & 63);
@@ -77,58 +102,48 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
         ah = (int)(t % AH);
         b = t / AH;
     }
-    const float* xb = x + b * (int64_t)g.Cin * g.H * g.W;
-    const int ihb = TR ? ah + dh0 : ah * g.sh - g.ph, iwb = TR ? aw + dw0 : aw * g.sw - g.pw;
+    // an invalid pixel gets a base row far outside the image, so its loads fail the bounds check like any halo tap
+    const int ihb = !pvalid ? -0x100000 : (TR ? ah + dh0 : ah * g.sh - g.ph), iwb = TR ? aw + dw0 : aw * g.sw - g.pw;
+    const float* xp = x + b * (int64_t)g.Cin * HW + (int64_t)ihb * g.W + iwb;  // only dereferenced in bounds
+    const int wq = __builtin_amdgcn_readfirstlane(wid);
+    __syncthreads();
 
-    float xr[4], wr[4];
+    float xr[4], wr[WJ];
     auto load_step = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            {   // activations: pixel = tid & 63, k column = (tid >> 6) + 4j
-                const int k = k0 + (tid >> 6) + 4 * j;
-                float v = 0.f;
-                if (pvalid && k < K) {
-                    const int ci = wd_div(k, inv_ntaps), ti = k - ci * ntaps;
-                    const int i_h = wd_div(ti, inv_nkw), i_w = ti - i_h * nkw;
-                    const int ih = TR ? ihb - i_h : ihb + i_h, iw = TR ? iwb - i_w : iwb + i_w;
-                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = xb[((int64_t)ci * g.H + ih) * g.W + iw];
-                }
-                xr[j] = v;
-            }
-            {   // weights: plain layout [n][ci][kh][kw] has k contiguous (k fastest over the lanes);
-                // transposed layout [ci][n][kh][kw] is walked with n fastest
-                const int kk = TR ? (tid >> 6) + 4 * j : (tid & 15);
-                const int n = TR ? (tid & 63) : (tid >> 4) + 16 * j;
-                const int k = k0 + kk;
-                float v = 0.f;
-                if (n0 + n < g.Cout && k < K) {
-                    const int ci = wd_div(k, inv_ntaps), ti = k - ci * ntaps;
-                    const int i_h = wd_div(ti, inv_nkw), i_w = ti - i_h * nkw;
-                    const int kh = TR ? kh0 + i_h * g.sh : i_h, kw = TR ? kw0 + i_w * g.sw : i_w;
-                    v = TR ? w[((int64_t)ci * g.Cout + n0 + n) * KK + kh * g.KW + kw]
-                           : w[((int64_t)(n0 + n) * g.Cin + ci) * KK + kh * g.KW + kw];
-                }
-                wr[j] = v;
+        for (int j = 0; j < 4; ++j) {  // activations: pixel = tid & 63, k column = wave + 4j (wave-uniform)
+            const int k = k0 + wq + 4 * j;
+            const int hw = kt_hw[k], delta = kt_delta[k];
+            const int ih = TR ? ihb - (hw >> 16) : ihb + (hw >> 16), iw = TR ? iwb - (hw & 0xffff) : iwb + (hw & 0xffff);
+            xr[j] = ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) ? xp[delta] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            if (!TR) {  // [n][K] row-major: k fastest over the lanes
+                const int k = k0 + (tid & 15), n = n0 + (tid >> 4) + 16 * j;
+                wr[j] = (n < g.Cout && k < K) ? w[(int64_t)n * K + k] : 0.f;
+            } else {    // [ci][n][kh][kw]: n fastest over the lanes
+                const int k = k0 + tid / NCH + (WD_THREADS / NCH) * j, n = n0 + tid % NCH;
+                wr[j] = (n < g.Cout && k < K) ? w[kt_w[k] + n * KK] : 0.f;
             }
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Xs[buf][(tid & 63) * WD_ST + (tid >> 6) + 4 * j] = xr[j];
-            const int kk = TR ? (tid >> 6) + 4 * j : (tid & 15);
-            const int n = TR ? (tid & 63) : (tid >> 4) + 16 * j;
-            Ws[buf][n * WD_ST + kk] = wr[j];
+        for (int j = 0; j < 4; ++j) Xs[buf][(tid & 63) * WD_ST + wq + 4 * j] = xr[j];
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            if (!TR) Ws[buf][((tid >> 4) + 16 * j) * WD_ST + (tid & 15)] = wr[j];
+            else Ws[buf][(tid % NCH) * WD_ST + tid / NCH + (WD_THREADS / NCH) * j] = wr[j];
         }
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[2][PXT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ch_half = wid >> 1, px_half = wid & 1;
-    const int nsteps = (K + 15) / 16;
+        for (int u = 0; u < PXT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ch0 = (CW == 2 ? (wid >> 1) : 0) * 32, px0 = (CW == 2 ? (wid & 1) * 32 : wid * 16);
     if (nsteps > 0) {
         load_step(0);
         store_step(0);
@@ -136,7 +151,21 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps) load_step((s + 1) * 16);  // in flight during the MFMAs below
-        wd_mfma_step(Ws[s & 1], Xs[s & 1], ch_half * 32, px_half * 32, li, lk, acc);
+        const float* Wb = Ws[s & 1];
+        const float* Xb = Xs[s & 1];
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+            float av[2], bv[PXT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = Wb[(ch0 + t * 16 + li) * WD_ST + k4 + lk];
+#pragma unroll
+            for (int u = 0; u < PXT; ++u) bv[u] = Xb[(px0 + u * 16 + li) * WD_ST + k4 + lk];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < PXT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+        }
         if (s + 1 < nsteps) store_step((s + 1) & 1);
         __syncthreads();
     }
@@ -144,8 +173,8 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
     // D: row (channel) = lk*4 + r, col (pixel) = li
     const int64_t ohw = (int64_t)g.OH * g.OW;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int64_t q = p0 + px_half * 32 + u * 16 + li;
+    for (int u = 0; u < PXT; ++u) {
+        const int64_t q = p0 + px0 + u * 16 + li;
         if (q >= npix) continue;
         const int qaw = (int)(q % AW);
         const int64_t t = q / AW;
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + ch_half * 32 + t2 * 16 + lk * 4 + r;
+                const int n = n0 + ch0 + t2 * 16 + lk * 4 + r;
                 if (n < g.Cout) {
                     float v = act_apply(acc[t2][u][r] + (bias != nullptr ? bias[n] : 0.f), act, slope);
                     if (accumulate) v += yp[n * ohw];
