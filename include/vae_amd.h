@@ -77,7 +77,9 @@ enum {
  *             `in`/`din` name that BN's INPUT and its gradient), 8 out_bn (save block of the virtual BN
  *             that follows, -1 none), 9 running_mean of that BN (statistics pivot); r6 then holds the
  *             per-chunk statistics slab (vae_conv_scratch_floats), 10 the op's own weight-gradient
- *             partial region (vae_conv_wgrad_partial_floats; backward only).
+ *             partial region (vae_conv_wgrad_partial_floats; backward only).  Without VAE_F_FUSED r[10] is
+ *             optional: a wide layer (>= 16 channels on the small side of its weight gradient) uses it for
+ *             split-reduction partials when present and falls back to float atomics when -1.
  *  BN         r: 0 in, 1 out, 2 din, 3 dout, 4 gamma, 5 beta, 6 save (WORK, 8*C floats: mean, rstd,
  *                scale|sum_dy/n, shift|sum_dy_xhat/n, a, b, c, spare), 7 running_mean, 8 running_var
  *                (STATE), 9 partials / slab (WORK, shared scratch).  VAE_F_FUSED: 1 and 3 are -1.
@@ -145,7 +147,8 @@ int vae_conv_forward_variant(const vae_op* op, int B);
  * slabs (+ the gathered data-parallel rows).  0 if not fusable. */
 int64_t vae_conv_scratch_floats(const vae_op* op, int B);
 /* Floats of the op's OWN weight-gradient partial region (r[10], WORK): one row per workgroup of the weight-gradient
- * kernel.  The regions of different layers must not overlap: their reduction is deferred to one launch at the
+ * kernel (fused path) or one copy of dw per slice of the reduction (wide layers off the fused path; 0 for layers
+ * that need none).  The regions of different layers must not overlap: their reduction is deferred to one launch at the
  * end of vae_run_backward. */
 int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B);
 

@@ -100,7 +100,7 @@ static inline void chunking(int B, int64_t per_sample, int* bchunk, int* nchunks
 // layers at least this wide (output rows x reduction length) take the K-loop MFMA kernels of wide.h
 #define WIDE_MIN_N 16
 #define WIDE_MIN_K 32
-#define WIDE_WG_BLOCKS 768  // split of the weight gradient's reduction: more workgroups = more float atomics per dw line
+#define WIDE_WG_BLOCKS 1536  // workgroups the weight gradient's reduction is split into (6 per CU)
 static FastDiv mk_fdiv(uint32_t d) {
     FastDiv f;
     f.d = d;
@@ -146,14 +146,15 @@ static int launch_conv_gather(const Ctx& c, const float* x, const float* w, cons
     const int gx = (int)ceil_div64(npix, 256);
     const int64_t K = (int64_t)g.Cin * g.KH * g.KW;
     if (wide_gather_ok(g, K, npix)) {
+        const int kpad = (int)ceil_div64(K, 16) * 16;
         if (g.Cout <= 32) {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32);
-            hipLaunchKernelGGL((wide_gather_k<false, 1>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                               accumulate);
+            hipLaunchKernelGGL((wide_gather_k<false, 1>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
         } else {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64);
-            hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                               accumulate);
+            hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
         }
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
@@ -176,14 +177,15 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
     const int gx = (int)ceil_div64(npix, 256);
     const int64_t K = (int64_t)g.Cin * ((g.KH + g.sh - 1) / g.sh) * ((g.KW + g.sw - 1) / g.sw);  // largest class
     if (wide_gather_ok(g, K, npix)) {
+        const int kpad = (int)ceil_div64(K, 16) * 16;
         if (g.Cout <= 32) {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32, g.sh * g.sw);
-            hipLaunchKernelGGL((wide_gather_k<true, 1>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                               accumulate);
+            hipLaunchKernelGGL((wide_gather_k<true, 1>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
         } else {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64, g.sh * g.sw);
-            hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 0, c.s, x, w, bias, y, c.B, g, act, slope,
-                               accumulate);
+            hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
         }
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
@@ -198,26 +200,48 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
     VAE_LAUNCH_CHECK("convT_gather_k");
     return VAE_OK;
 }
-// dw[a][cc][kh][kw] += sum S[b,a,oh,ow] * G[b,cc,oh*sh-ph+kh,...]
+// split of the wide weight-gradient GEMM (wide.h): grid = chunks x ceil(A/64) x ceil(C*KH*KW/64)
+struct WideWgPlan {
+    bool ok;
+    int gy, gz;
+    int64_t chunks, chunk, R, NK;
+};
+static WideWgPlan wide_wgrad_plan(int B, int A, int SH, int SW, int C, int KH, int KW) {
+    WideWgPlan p;
+    p.R = (int64_t)B * SH * SW;
+    p.NK = (int64_t)C * KH * KW;
+    p.ok = A >= WIDE_MIN_N && p.NK >= WIDE_MIN_K && p.R < (1ll << 31) && p.R * SH * SW < (1ll << 32) && p.NK < (1 << 24);
+    p.gy = (A + 63) / 64;
+    p.gz = (int)ceil_div64(p.NK, 64);
+    const int64_t want = ceil_div64(WIDE_WG_BLOCKS, (int64_t)p.gy * p.gz);
+    p.chunk = ceil_div64(ceil_div64(p.R, want), 16) * 16;
+    if (p.chunk < 256) p.chunk = 256;  // >= 16 K steps per workgroup
+    p.chunks = ceil_div64(p.R, p.chunk);
+    return p;
+}
+// dw[a][cc][kh][kw] += sum S[b,a,oh,ow] * G[b,cc,oh*sh-ph+kh,...]; part: the op's own partial region (r[10]) or nullptr
 static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw, int A, int SH, int SW, int C,
-                        int GH, int GW, int KH, int KW, int sh, int sw, int ph, int pw) {
+                        int GH, int GW, int KH, int KW, int sh, int sw, int ph, int pw, float* part) {
     const int64_t R = (int64_t)c.B * SH * SW;
-    const int64_t NK = (int64_t)C * KH * KW;
-    if (A >= WIDE_MIN_N && NK >= WIDE_MIN_K && R < (1ll << 31) && R * SH * SW < (1ll << 32) && NK < (1 << 24)) {
+    const WideWgPlan wp = wide_wgrad_plan(c.B, A, SH, SW, C, KH, KW);
+    if (wp.ok) {
         WideWgArgs a;
-        a.S = S; a.G = G; a.dw = dw;
+        a.S = S; a.G = G; a.dw = dw; a.part = part;
         a.B = c.B; a.A = A; a.SH = SH; a.SW = SW; a.C = C; a.GH = GH; a.GW = GW; a.KH = KH; a.KW = KW;
         a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
-        const int gy = (A + 63) / 64, gz = (int)ceil_div64(NK, 64);
-        int64_t chunks = ceil_div64(WIDE_WG_BLOCKS, (int64_t)gy * gz);
-        int64_t chunk = ceil_div64(ceil_div64(R, chunks), 16) * 16;
-        if (chunk < 256) chunk = 256;                               // >= 16 K steps before paying the atomics
-        a.R = R; a.chunk = chunk;
+        a.R = R; a.chunk = wp.chunk;
         a.d_SHW = mk_fdiv((uint32_t)(SH * SW)); a.d_SW = mk_fdiv((uint32_t)SW);
         a.d_KK = mk_fdiv((uint32_t)(KH * KW)); a.d_KW = mk_fdiv((uint32_t)KW);
-        dim3 grid((unsigned)ceil_div64(R, chunk), gy, gz);
+        dim3 grid((unsigned)wp.chunks, wp.gy, wp.gz);
         hipLaunchKernelGGL(wide_wgrad_k, grid, dim3(WD_THREADS), 0, c.s, a);
         VAE_LAUNCH_CHECK("wide_wgrad_k");
+        if (part != nullptr) {
+            const int64_t n = (int64_t)A * wp.NK;
+            const int split = (int)(wp.chunks >= 128 ? 8 : wp.chunks >= 32 ? 4 : 1);
+            hipLaunchKernelGGL(wide_wgrad_reduce_k, dim3((unsigned)ceil_div64(n, 64), split), dim3(256), 0, c.s, part, dw, n,
+                               (int)wp.chunks);
+            VAE_LAUNCH_CHECK("wide_wgrad_reduce_k");
+        }
         return VAE_OK;
     }
     const int AT = 4, TG = (KH * KW <= 9) ? 9 : 16;
@@ -273,6 +297,13 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     float* dw = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), nw, "conv.dw", &ok);
     float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), g.Cout, "conv.db", &ok);
     float* part = resolve(c, op.r[6], (int64_t)2 * g.Cout * VAE_MAX_CHUNKS, "conv.partials", &ok);
+    // optional own region for the wide weight-gradient kernel's partial sums (else: float atomics)
+    const bool T = op.kind == VAE_OP_CONVT;
+    const WideWgPlan wp = T ? wide_wgrad_plan(c.B, g.Cin, g.H, g.W, g.Cout, g.KH, g.KW)
+                            : wide_wgrad_plan(c.B, g.Cout, g.OH, g.OW, g.Cin, g.KH, g.KW);
+    float* wpart = (wp.ok && op.r[10] >= 0)
+                       ? resolve(c, op.r[10], wp.chunks * wp.NK * (T ? g.Cin : g.Cout), "conv.wgrad_partials", &ok)
+                       : nullptr;
     if (!ok) return VAE_EINVAL;
 
     // 1) dy <- dy * act'(y) in place, bias gradient = per-channel sum
@@ -288,7 +319,7 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     }
     // 2) weight gradient, 3) input gradient
     if (op.kind == VAE_OP_CONV) {
-        rc = launch_wgrad(c, dy, x, dw, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+        rc = launch_wgrad(c, dy, x, dw, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, wpart);
         if (rc) return rc;
         if (dx != nullptr) {
             ConvGeom t = g;  // transposed-conv orientation: (Cout,OH,OW) -> (Cin,H,W)
@@ -296,7 +327,7 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
             rc = launch_convT_gather(c, dy, w, nullptr, dx, t, VAE_ACT_NONE, 0.f, op.flags & VAE_F_ACC_DIN);
         }
     } else {
-        rc = launch_wgrad(c, x, dy, dw, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
+        rc = launch_wgrad(c, x, dy, dw, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, wpart);
         if (rc) return rc;
         if (dx != nullptr) {
             ConvGeom t = g;  // conv orientation: (Cout,OH,OW) -> (Cin,H,W)
@@ -573,6 +604,11 @@ extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
     if (check_geom(*op) != VAE_OK) return 0;
     const ConvGeom g = geom_of(*op);
     const int T = op->kind == VAE_OP_CONVT;
+    if (!conv_igemm_fits(*op, B)) {  // not on the fused path: the wide weight-gradient kernel's [chunk][dw] partials
+        const WideWgPlan p = T ? wide_wgrad_plan(B, g.Cin, g.H, g.W, g.Cout, g.KH, g.KW)
+                               : wide_wgrad_plan(B, g.Cout, g.OH, g.OW, g.Cin, g.KH, g.KW);
+        return p.ok ? p.chunks * p.NK * (T ? g.Cin : g.Cout) : 0;
+    }
     const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     return w.SB < 1 ? 0 : wgrad_part_floats(w, B);

@@ -46,15 +46,17 @@ __device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, i
 template <bool TR, int CW>
 __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                            ConvGeom g, int act, float slope, int accumulate) {
+                                                            ConvGeom g, int act, float slope, int accumulate,
+                                                            int kpad) {
     constexpr int NCH = 32 * CW;  // channels per tile
     constexpr int WJ = 2 * CW;    // weight elements a thread fills per K step
     constexpr int PXT = CW;       // 16-pixel tiles per wave
     __shared__ float Ws[2][NCH * WD_ST];  // [channel][k]
     __shared__ float Xs[2][64 * WD_ST];   // [pixel][k]
-    __shared__ int kt_delta[WD_KTAB_MAX]; // k -> offset of its tap from the pixel's base address
-    __shared__ int kt_hw[WD_KTAB_MAX];    // k -> (i_h << 16) | i_w, tap position for the bounds check
-    __shared__ int kt_w[TR ? WD_KTAB_MAX : 1];  // k -> weight offset without the output channel (transposed layout)
+    extern __shared__ int wd_kt[];          // tap tables, `kpad` entries each (kpad = longest class reduction, padded to 16)
+    int* const kt_delta = wd_kt;            // k -> offset of its tap from the pixel's base address
+    int* const kt_hw = wd_kt + kpad;        // k -> (i_h << 16) | i_w, tap position for the bounds check
+    int* const kt_w = wd_kt + 2 * kpad;     // k -> weight offset without the output channel (transposed layout only)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
 
@@ -200,6 +202,7 @@ struct WideWgArgs {
     const float* S;  // [B][A][SH][SW]
     const float* G;  // [B][C][GH][GW]
     float* dw;       // [A][C][KH][KW]
+    float* part;     // [grid.x][A][C][KH][KW] partial sums (reduced by wide_wgrad_reduce_k), or nullptr: float atomics into dw
     int B, A, SH, SW, C, GH, GW, KH, KW, sh, sw, ph, pw;
     int64_t R, chunk;       // reduction length B*SH*SW and the slice of it one grid.x index takes
     FastDiv d_SHW, d_SW, d_KK, d_KW;
@@ -286,6 +289,31 @@ __global__ __launch_bounds__(WD_THREADS) void wide_wgrad_k(WideWgArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int aa = a0 + a_half * 32 + t * 16 + lk * 4 + r;
                 const int n = n0 + n_half * 32 + u * 16 + li;
-                if (aa < a.A && n < NK) atomicAdd(&a.dw[(int64_t)aa * NK + n], acc[t][u][r]);
+                if (aa < a.A && n < NK) {
+                    if (a.part != nullptr) a.part[((int64_t)blockIdx.x * a.A + aa) * NK + n] = acc[t][u][r];
+                    else atomicAdd(&a.dw[(int64_t)aa * NK + n], acc[t][u][r]);
+                }
             }
+}
+
+// dw[e] += sum over rows of part[row][e]: 64 elements x 4 row lanes per workgroup, grid.y further splits the rows
+// (a handful of float atomics per element at the end instead of one per workgroup of the gradient kernel).
+__global__ __launch_bounds__(256) void wide_wgrad_reduce_k(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int64_t n, int rows) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        const int step = 4 * gridDim.y;
+        int r = blockIdx.y * 4 + ty;
+        for (; r + step < rows; r += 2 * step) {
+            s0 += part[(int64_t)r * n + e];
+            s1 += part[(int64_t)(r + step) * n + e];
+        }
+        if (r < rows) s0 += part[(int64_t)r * n + e];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && e < n) atomicAdd(&dw[e], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }

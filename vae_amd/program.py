@@ -178,6 +178,10 @@ class ProgramBuilder:
                 self.scratch_need = max(self.scratch_need, lib.vae_conv_scratch_floats(ctypes.byref(op), self.B))
                 if self.want_grads:  # the layer's own weight-gradient partials (reduced in one launch at the end)
                     op.r[10] = self.fixed(lib.vae_conv_wgrad_partial_floats(ctypes.byref(op), self.B))
+            elif op.kind in convs and self.want_grads:
+                n = lib.vae_conv_wgrad_partial_floats(ctypes.byref(op), self.B)
+                if n > 0:  # wide layer: split-reduction partials of its weight gradient
+                    op.r[10] = self.fixed(n)
         out_refs = {buf.ref for buf, _ in self.outputs.values()}
         for bn in self.ops:
             if bn.kind != L.OP_BN or bn.r[1] in out_refs:
