@@ -13,6 +13,8 @@ enum { CR_STATS = 0, CR_ACTBWD = 1, CR_BNBWD = 2 };
 //            numerically robust variance when |mean| >> std)
 // CR_ACTBWD: g = dy * act'(y); dy <- g (in place); s1 = sum(g)       (bias gradient)
 // CR_BNBWD : g = dout * (relu ? out > 0 : 1); dout <- g; s1 = sum(g); s2 = sum(g * xhat)
+// A chunk holds < 2^31 elements (host-checked), so the element loop runs on 32-bit indices: the 64-bit
+// division the flat index would need costs more than the loads.
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ x, float* __restrict__ dy,
                                                      const float* __restrict__ y, const float* __restrict__ save,
@@ -29,11 +31,12 @@ __global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ x
         mean = save[c];
         rstd = save[C + c];
     }
-    const int64_t n = (int64_t)(b1 - b0) * HW;
-    for (int64_t q = threadIdx.x; q < n; q += blockDim.x) {
-        const int64_t b = b0 + q / HW;
-        const int i = (int)(q % HW);
-        const int64_t idx = (b * C + c) * HW + i;
+    const int n = (b1 - b0) * HW;
+    const int64_t base = ((int64_t)b0 * C + c) * HW;  // element (b0, c, 0)
+    const int skip = (C - 1) * HW;                    // added per sample crossed
+    auto one = [&](int q) {
+        const int bb = (int)((unsigned)q / (unsigned)HW);
+        const int64_t idx = base + q + (int64_t)bb * skip;
         if (MODE == CR_STATS) {
             const float v = x[idx] - pivot;
             s1 += v;
@@ -55,7 +58,15 @@ __global__ __launch_bounds__(256) void chan_reduce_k(const float* __restrict__ x
             s1 += g;
             s2 = fmaf(g, xh, s2);
         }
+    };
+    int q = threadIdx.x;
+    for (; q + 768 < n; q += 1024) {  // four independent element streams in flight
+        one(q);
+        one(q + 256);
+        one(q + 512);
+        one(q + 768);
     }
+    for (; q < n; q += 256) one(q);
     const float t1 = block_sum_256(s1, sm);
     const float t2 = block_sum_256(s2, sm);
     if (threadIdx.x == 0) {
@@ -113,8 +124,9 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, f
                                                   const float* __restrict__ save, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int64_t total, int C, int HW,
                                                   int relu) {
+    const bool small = total < ((int64_t)1 << 31);  // 32-bit index arithmetic when the tensor allows it
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i / HW) % C);
+        const int c = small ? (int)(((unsigned)i / (unsigned)HW) % (unsigned)C) : (int)((i / HW) % C);
         const float sc = save[C + c] * gamma[c];
         float v = fmaf(x[i] - save[c], sc, beta[c]);
         if (relu) v = v > 0.f ? v : 0.f;
@@ -169,8 +181,9 @@ __global__ void bn_bwd_rows_k(const float* __restrict__ rows, int world, const f
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ x, const float* __restrict__ g,
                                                       float* __restrict__ dx, const float* __restrict__ save,
                                                       const float* __restrict__ gamma, int64_t total, int C, int HW) {
+    const bool small = total < ((int64_t)1 << 31);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i / HW) % C);
+        const int c = small ? (int)(((unsigned)i / (unsigned)HW) % (unsigned)C) : (int)((i / HW) % C);
         const float rstd = save[C + c];
         const float xh = (x[i] - save[c]) * rstd;
         dx[i] = gamma[c] * rstd * (g[i] - save[2 * C + c] - xh * save[3 * C + c]);

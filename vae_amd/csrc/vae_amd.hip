@@ -86,15 +86,20 @@ static inline int ew_grid(int64_t n) {
     if (g < 1) g = 1;
     return (int)g;
 }
-// batch chunking for the two-stage channel reductions
-static inline void chunking(int B, int64_t per_sample, int* bchunk, int* nchunks) {
-    // aim for >= ~16k elements per block, at most VAE_MAX_CHUNKS chunks
-    int64_t want = ceil_div64((int64_t)B * per_sample, 16384);
+// batch chunking for the two-stage channel reductions (grid = C x chunks workgroups)
+static inline int chunking(int B, int C, int64_t per_sample, int* bchunk, int* nchunks) {
+    // ~8k elements per workgroup, at least ~1024 workgroups over the channels, at most VAE_MAX_CHUNKS chunks
+    int64_t want = ceil_div64((int64_t)B * per_sample, 8192);
+    const int64_t fill = ceil_div64(1024, C);
+    if (want < fill) want = fill;
     if (want > VAE_MAX_CHUNKS) want = VAE_MAX_CHUNKS;
     if (want < 1) want = 1;
     if (want > B) want = B;
     *bchunk = (int)ceil_div64(B, want);
     *nchunks = (int)ceil_div64(B, *bchunk);
+    if ((int64_t)*bchunk * per_sample >= ((int64_t)1 << 31))  // chan_reduce_k indexes a chunk with 32 bits
+        VAE_FAIL(VAE_EINVAL, "channel reduction: %lld elements per chunk exceed 2^31", (long long)*bchunk * per_sample);
+    return VAE_OK;
 }
 
 // layers at least this wide (output rows x reduction length) take the K-loop MFMA kernels of wide.h
@@ -287,7 +292,7 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     const int64_t nin = (int64_t)c.B * g.Cin * g.H * g.W, nout = (int64_t)c.B * g.Cout * g.OH * g.OW;
     const int64_t nw = (int64_t)g.Cin * g.Cout * g.KH * g.KW;
     int bchunk, nchunks;
-    chunking(c.B, (int64_t)g.OH * g.OW, &bchunk, &nchunks);
+    if ((rc = chunking(c.B, g.Cout, (int64_t)g.OH * g.OW, &bchunk, &nchunks)) != VAE_OK) return rc;
     const float* x = resolve(c, op.r[0], nin, "conv.in", &ok);
     const float* y = resolve(c, op.r[1], nout, "conv.out", &ok);
     float* dx = resolve_opt(c, op.r[2], nin, "conv.din", &ok);
@@ -905,7 +910,7 @@ static int bn_forward(const Ctx& c, const vae_op& op, int training) {
     if (!ok) return VAE_EINVAL;
     if (training) {
         int bchunk, nchunks;
-        chunking(c.B, HW, &bchunk, &nchunks);
+        if (chunking(c.B, C, HW, &bchunk, &nchunks) != VAE_OK) return VAE_EINVAL;
         hipLaunchKernelGGL(chan_reduce_k<CR_STATS>, dim3(C, nchunks), dim3(256), 0, c.s, x, nullptr, nullptr, nullptr,
                            part, c.B, C, HW, bchunk, 0, 0.f, 0);
         VAE_LAUNCH_CHECK("chan_reduce_k<STATS>");
@@ -950,7 +955,7 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
     float* part = resolve(c, op.r[9], (int64_t)2 * C * VAE_MAX_CHUNKS, "bn.partials", &ok);
     if (!ok) return VAE_EINVAL;
     int bchunk, nchunks;
-    chunking(c.B, HW, &bchunk, &nchunks);
+    if (chunking(c.B, C, HW, &bchunk, &nchunks) != VAE_OK) return VAE_EINVAL;
     hipLaunchKernelGGL(chan_reduce_k<CR_BNBWD>, dim3(C, nchunks), dim3(256), 0, c.s, x, dy, y, save, part, c.B, C, HW,
                        bchunk, 0, 0.f, (op.flags & VAE_F_BN_RELU) ? 1 : 0);
     VAE_LAUNCH_CHECK("chan_reduce_k<BNBWD>");
