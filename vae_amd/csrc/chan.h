@@ -82,13 +82,16 @@ __global__ void bn_stats_finalize_k(const float* __restrict__ x, const float* __
                                     float* __restrict__ save, float* __restrict__ rmean, float* __restrict__ rvar,
                                     int C, int HW, int nchunks, int64_t n, float eps, float momentum,
                                     float* __restrict__ row_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one 64-lane workgroup per channel: the lanes take the chunks, a fixed shuffle tree adds them
+    const int c = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
+    for (int k = threadIdx.x; k < nchunks; k += 64) {
         s1 += partials[((int64_t)k * C + c) * 2];
         s2 += partials[((int64_t)k * C + c) * 2 + 1];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     const float pivot = x[(int64_t)c * HW];
     const float inv_n = 1.f / (float)n;
     const float dm = s1 * inv_n;
@@ -138,13 +141,15 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, f
 __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, float* __restrict__ save,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int nchunks,
                                   int64_t n, float* __restrict__ row_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;  // one 64-lane workgroup per channel, as in bn_stats_finalize_k
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
+    for (int k = threadIdx.x; k < nchunks; k += 64) {
         s1 += partials[((int64_t)k * C + c) * 2];
         s2 += partials[((int64_t)k * C + c) * 2 + 1];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     if (row_out != nullptr) {  // data-parallel: this rank's {sum g, sum g*xhat, n} row
         row_out[c * 4] = s1;
         row_out[c * 4 + 1] = s2;
@@ -193,9 +198,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const float* __restrict__ 
 // bias gradient finalize: db[c] = sum over chunks of partial s1
 __global__ void bias_grad_finalize_k(const float* __restrict__ partials, float* __restrict__ db, int C,
                                      int nchunks) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;  // one 64-lane workgroup per channel
     float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partials[((int64_t)k * C + c) * 2];
-    db[c] = s;
+    for (int k = threadIdx.x; k < nchunks; k += 64) s += partials[((int64_t)k * C + c) * 2];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) db[c] = s;
 }
