@@ -172,6 +172,13 @@ int vae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * advanced on the device (replaces torch.randn_like at vae.py:17). */
 int vae_randn(float* out, int64_t n, uint64_t* rng, vae_stream_t stream);
 
+/* Batched slidingWindow.__getitem__ (train.py:21-32) on a series resident in HBM:
+ * out[b][c][l] = series[c*T + starts[b] + l] for b < B, c < C, l < L; starts: B device int64 window indices.
+ * A start outside [0, T-L] (the reference returns None there) yields NaNs.  Replaces the DataLoader collate +
+ * host-to-device copy in front of train.py:57. */
+int vae_window_gather(const float* series, int C, int64_t T, int L, const int64_t* starts, int B, float* out,
+                      vae_stream_t stream);
+
 /* hipGraph capture of an arbitrary sequence of the calls above: begin, issue calls on the
  * returned stream, end -> handle; launch replays on `stream`. */
 int vae_graph_begin(vae_stream_t* capture_stream);

@@ -253,3 +253,46 @@ def test_device_randn_moments():
     assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
     assert abs((a * a * a).mean().item()) < 2e-2 and abs((a ** 4).mean().item() - 3) < 5e-2
     assert not torch.equal(a, b) and int(rng[1].item()) == 2 * (1 << 18)
+
+
+def test_device_sliding_window_matches_reference_loader():
+    """vae_window_gather / DeviceSlidingWindow vs DataLoader(slidingWindow(data, L)) (train.py:21-32): same
+    batches in order, ragged last batch, shuffled epoch covers every window once, invalid start -> NaN."""
+    from torch.utils.data import DataLoader
+    from vae_amd.train import DeviceSlidingWindow, slidingWindow
+    gen = torch.Generator().manual_seed(5)
+    data = torch.randn(3, 500, generator=gen)
+    Lw, bs = 60, 64
+    ref = list(DataLoader(slidingWindow(data, Lw), batch_size=bs, shuffle=False))
+    dev = DeviceSlidingWindow(data, Lw, batch_size=bs, device=DEV)
+    assert len(dev) == len(ref) and len(dev.dataset) == 440
+    got = list(dev)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and torch.equal(g.cpu(), r)     # a gather: bit-exact
+    assert len(DeviceSlidingWindow(data, Lw, batch_size=bs, drop_last=True, device=DEV)) == 440 // bs
+    sh = DeviceSlidingWindow(data, Lw, batch_size=bs, shuffle=True, device=DEV)
+    firsts = torch.cat([b[:, 0, 0] for b in sh]).cpu()
+    assert sorted(firsts.tolist()) == sorted(data[0, :440].tolist())
+    edge = dev.gather(torch.tensor([440, 441, -1, 0]))
+    assert torch.equal(edge[0].cpu(), data[:, 440:500]) and torch.isnan(edge[1]).all() and torch.isnan(edge[2]).all()
+    assert torch.equal(edge[3].cpu(), data[:, :60])
+
+
+def test_train_epoch_from_device_windows():
+    """train() (train.py:51-72 signature) fed by the on-device window loader: runs the fused step per batch and
+    returns the epoch's average loss; the first step's loss equals the oracle's on the same first batch."""
+    import vae_amd
+    from vae_amd.train import DeviceSlidingWindow, criterion, train
+    torch.manual_seed(0)
+    model = vae_amd.VariationalAutoencoder(input_size=3, hidden_size=30, num_layers=3, latent_dims=15,
+                                           v_encoder=vae_amd.Encoders.LongShort_TCVAE_Encoder,
+                                           v_decoder=vae_amd.Decoders.LongShort_TCVAE_Decoder,
+                                           L=60, slope=0.2, first_kernel=21).to(DEV)
+    opt = vae_amd.optim.Adam(model.parameters(), lr=1e-3)
+    t = torch.arange(700, dtype=torch.float32)
+    data = torch.stack([50 + 10 * torch.sin(t / 17 + c) + torch.randn(700) for c in range(3)])
+    loader = DeviceSlidingWindow(data, 60, batch_size=128, drop_last=True, device=DEV)
+    avg1 = train(model, loader, criterion, opt, DEV, 1)
+    avg2 = train(model, loader, criterion, opt, DEV, 2)
+    assert avg1 == avg1 and avg2 < avg1, (avg1, avg2)      # finite, and the ELBO goes down

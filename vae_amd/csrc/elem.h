@@ -212,3 +212,22 @@ __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t 
 __global__ void rng_advance_k(uint64_t* rng, uint64_t nquad) {
     if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += nquad;
 }
+
+// ---- sliding windows of a resident series ---------------------------------------------------
+// out[b][c][l] = series[c][starts[b] + l]: slidingWindow.__getitem__ (train.py:25-28) for a whole batch on the
+// device; the DataLoader's collate + host-to-device copy of B*C*L floats becomes a gather from the (C, T) series
+// that stays in HBM (windows overlap by L-1 samples, so the series is L times smaller than an epoch of windows).
+// A start the reference would answer with None (start + L > T, or negative) yields NaNs.
+__global__ __launch_bounds__(256) void window_gather_k(const float* __restrict__ series,
+                                                       const int64_t* __restrict__ starts, float* __restrict__ out,
+                                                       int C, int64_t T, int L, int B) {
+    const int per = C * L;
+    const int64_t total = (int64_t)B * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per;
+        const int r = (int)(i - b * per);
+        const int c = r / L, l = r - c * L;
+        const int64_t s = starts[b];
+        out[i] = (s >= 0 && s + L <= T) ? series[(int64_t)c * T + s + l] : __builtin_nanf("");
+    }
+}

@@ -1328,6 +1328,16 @@ extern "C" int vae_randn(float* out, int64_t n, uint64_t* rng, vae_stream_t stre
     return VAE_OK;
 }
 
+extern "C" int vae_window_gather(const float* series, int C, int64_t T, int L, const int64_t* starts, int B, float* out,
+                                 vae_stream_t stream) {
+    if (!series || !starts || !out || C < 1 || L < 1 || T < L || B < 1 || (int64_t)C * L >= ((int64_t)1 << 31))
+        VAE_FAIL(VAE_EINVAL, "window_gather: bad argument (C=%d T=%lld L=%d B=%d)", C, (long long)T, L, B);
+    hipLaunchKernelGGL(window_gather_k, dim3(ew_grid((int64_t)B * C * L)), dim3(256), 0, (hipStream_t)stream, series,
+                       starts, out, C, T, L, B);
+    VAE_LAUNCH_CHECK("window_gather_k");
+    return VAE_OK;
+}
+
 // ---- hipGraph capture -------------------------------------------------------------------------
 static thread_local hipStream_t g_capture_stream = nullptr;
 

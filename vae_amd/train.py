@@ -33,6 +33,50 @@ class slidingWindow(Dataset):
         return self.data.shape[1] - self.L
 
 
+class DeviceSlidingWindow:
+    """`DataLoader(slidingWindow(data, L), batch_size, shuffle)` with the series resident on the GPU.
+
+    Yields (B, C, L) device batches gathered by one HIP kernel (vae_window_gather) from the (C, T) series, so an
+    epoch moves T*C floats over PCIe once instead of (T-L)*C*L per epoch, and no collate runs on the host.
+    Iteration order: `arange(T-L)`, or `torch.randperm` on the device when shuffle (same distribution as the
+    DataLoader's RandomSampler, not the same permutation).  `.dataset` is the reference Dataset (train.py:21-32),
+    so `train()` / `test()` print and normalise by `len(loader.dataset)` as before.
+    """
+
+    def __init__(self, data, L, batch_size=1, shuffle=False, drop_last=False, device="cuda", generator=None):
+        data = torch.as_tensor(data, dtype=torch.float32)
+        if data.dim() != 2 or data.shape[1] <= L:
+            raise ValueError(f"DeviceSlidingWindow: need a (C, T) series with T > L, got {tuple(data.shape)}, L={L}")
+        self.dataset = slidingWindow(data, L)
+        self.series = data.to(device).contiguous()
+        self.L, self.batch_size, self.shuffle, self.drop_last = L, int(batch_size), shuffle, drop_last
+        self.generator = generator
+        self.n = data.shape[1] - L
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
+
+    def gather(self, starts, out=None):
+        """starts: int64 window indices (device) -> (len(starts), C, L) batch; `out` may be a preallocated buffer."""
+        L.require_device(self.series)
+        starts = starts.to(device=self.series.device, dtype=torch.int64).contiguous()
+        C, T = self.series.shape
+        B = starts.numel()
+        if out is None:
+            out = torch.empty(B, C, self.L, dtype=torch.float32, device=self.series.device)
+        assert out.is_contiguous() and out.numel() == B * C * self.L and out.dtype == torch.float32
+        L.check(L.lib().vae_window_gather(self.series.data_ptr(), C, T, self.L, starts.data_ptr(), B, out.data_ptr(),
+                                          L.stream_ptr()), "vae_window_gather")
+        return out
+
+    def __iter__(self):
+        dev = self.series.device
+        order = torch.randperm(self.n, device=dev, generator=self.generator) if self.shuffle \
+            else torch.arange(self.n, device=dev)
+        for i in range(len(self)):
+            yield self.gather(order[i * self.batch_size:(i + 1) * self.batch_size])
+
+
 # ------------------------------------------------------------------------------- criterion
 class _ElboFn(torch.autograd.Function):
     @staticmethod
