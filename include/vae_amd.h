@@ -120,6 +120,13 @@ int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int
                     int n_bases, int B, int training, vae_stream_t stream);
 int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                      int n_bases, int B, vae_stream_t stream);
+/* Backward over ops[op_begin, op_end) only (in reverse), with every weight gradient of the range complete when
+ * the call's work is: a data-parallel host runs the decoder's range first, starts the all-reduce of that bucket
+ * of the GRAD buffer on a side stream, and runs the encoder's range meanwhile (no counterpart in the reference,
+ * which is single-device: SURVEY.md 8e).  zero_grads != 0 clears the GRAD space first (the first range of a
+ * step); vae_run_backward == range [0, n_ops) with zero_grads = 1. */
+int vae_run_backward_range(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                           int n_bases, int B, vae_stream_t stream, int op_begin, int op_end, int zero_grads);
 /* Profiling twin of vae_run_forward: a HIP event is recorded on `stream` before every op and after the
  * last one; op_ms[i] (n_ops floats, host memory) receives the device time of op i in milliseconds.
  * Synchronises the stream, so it cannot be captured.  bench.py measures the dominant kernel with it. */

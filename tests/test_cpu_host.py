@@ -99,3 +99,30 @@ def test_program_layout_is_consistent():
         for r in op.r:
             if r >= 0 and (r >> 56) in sizes:
                 assert (r & ((1 << 56) - 1)) < sizes[r >> 56]
+
+
+def test_gradient_buckets_split_at_the_reparameterisation():
+    """DataParallelTrainStep's two gradient buckets (vae_run_backward_range): decoder + loss ops first, then the
+    encoder; the flat-buffer ranges partition the parameters at the first decoder parameter."""
+    from vae_amd.program import ProgramBuilder
+    for stem in ("mnist_lat15", "multiscale_c3_l60", "tcvae_c3_n3_l60_fk21"):
+        m = _build(stem)
+        m._param_off, off = {}, 0
+        names = []
+        for n, p in m.named_parameters():
+            m._param_off[id(p)] = off
+            names.append((n, off))
+            off += (p.numel() + 3) // 4 * 4
+        m._state_off, soff = {}, 0
+        for b_ in m._float_buffers():
+            m._state_off[id(b_)] = soff
+            soff += (b_.numel() + 3) // 4 * 4
+        b = ProgramBuilder(32, m._param_off, m._state_off)
+        m.emit_program(b, True)
+        prog = b.build()
+        buckets = prog.grad_buckets()
+        assert buckets is not None, stem
+        (b0, e0, lo0, hi0), (b1, e1, lo1, hi1) = buckets
+        assert e0 == prog.n_ops and b0 == e1 and b1 == 0          # backward order, every op exactly once
+        first_dec = min(o for n, o in names if n.startswith("decoder"))
+        assert lo0 == first_dec and hi0 is None and (lo1, hi1) == (0, first_dec), (stem, buckets, first_dec)

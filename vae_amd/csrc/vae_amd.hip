@@ -1258,15 +1258,17 @@ extern "C" int vae_time_forward(const vae_op* ops, int n_ops, float* const* base
     return rc;
 }
 
-extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
-                                int n_bases, int B, vae_stream_t stream) {
+extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                                      int n_bases, int B, vae_stream_t stream, int op_begin, int op_end, int zero_grads) {
     Ctx c;
     int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
     if (rc) return rc;
     if (bases[2] == nullptr) VAE_FAIL(VAE_EINVAL, "backward needs the GRAD space (2) bound");
+    if (op_begin < 0 || op_end > n_ops || op_begin > op_end)
+        VAE_FAIL(VAE_EINVAL, "backward: op range [%d, %d) outside the program of %d ops", op_begin, op_end, n_ops);
     // weight gradients accumulate with atomics: start from zero
-    VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
-    for (int i = n_ops - 1; i >= 0 && rc == VAE_OK; --i) {
+    if (zero_grads) VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
+    for (int i = op_end - 1; i >= op_begin && rc == VAE_OK; --i) {
         const vae_op& op = ops[i];
         switch (op.kind) {
             case VAE_OP_CONV:
@@ -1282,6 +1284,10 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
     if (rc == VAE_OK) rc = flush_wgrad_finalize(c);
     if (rc == VAE_OK) rc = flush_linear_wgrads(c);
     return rc;
+}
+extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                                int n_bases, int B, vae_stream_t stream) {
+    return vae_run_backward_range(ops, n_ops, bases, base_sizes, n_bases, B, stream, 0, n_ops, 1);
 }
 
 // ---- standalone criterion, optimiser, rng ---------------------------------------------------

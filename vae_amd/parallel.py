@@ -61,6 +61,15 @@ class Collective:
             dist.all_gather_into_tensor(rows.view(-1), mine.view(-1), group=self.group)
         return rows
 
+    def all_reduce_sum_async(self, t):
+        """Starts the in-place SUM of `t` and returns a handle whose wait() orders the current stream after it.
+        On RCCL the collective runs on the process group's own stream, behind the work already enqueued on the
+        current stream, so kernels enqueued next overlap with it.  Staged/CPU groups reduce synchronously."""
+        if t.is_cuda and self.backend != "gloo":
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.all_reduce_sum(t)
+        return None
+
     def all_reduce_sum(self, t):
         """In-place SUM over the ranks (the loss is reduction='sum', so gradients add, not average)."""
         if self._staged(t):
@@ -77,8 +86,10 @@ class DataParallelTrainStep(FusedTrainStep):
 
     `B` is the per-rank batch.  The step is enqueued eagerly on the current stream (collectives are
     not captured): randn, forward (+ one all-gather of 4*C floats per BatchNorm), ELBO, backward
-    (+ one all-gather per BatchNorm), all-reduce SUM of the flat gradient buffer (one bucket: 413 KB for
-    the MNIST model), Adam.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
+    (+ one all-gather per BatchNorm), all-reduce SUM of the flat gradient buffer, Adam.  The gradient goes in two
+    buckets: backward runs the decoder's ops first (vae_run_backward_range), the all-reduce of the decoder's
+    slice of the flat buffer starts on RCCL's stream, and the encoder's backward runs meanwhile; the encoder's
+    bucket follows.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
 
     def __init__(self, model, optimizer, B, device, bce=None, group=None):
         super().__init__(model, optimizer, B, device, bce=bce, use_graph=False)
@@ -92,6 +103,7 @@ class DataParallelTrainStep(FusedTrainStep):
         self.rng[0] ^= (self.coll.rank + 1) * 0x9E3779B1  # a different eps stream per rank
         self._hook_error = None
         self._hook = L.ALLGATHER_FN(self._allgather_hook)  # keep the thunk alive
+        self.buckets = self.prog.grad_buckets()  # None: parameters interleave, one bucket
 
     def _broadcast(self, t):
         if self.coll._staged(t):
@@ -120,7 +132,15 @@ class DataParallelTrainStep(FusedTrainStep):
         L.check(lib.vae_set_collective(self._hook, None, self.coll.rank, self.coll.world), "vae_set_collective")
         try:
             self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
-            self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
+            pending = []
+            if self.buckets is None:
+                self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
+                pending.append(self.coll.all_reduce_sum_async(self.grads))
+            else:
+                for i, (begin, end, lo, hi) in enumerate(self.buckets):
+                    self.prog.backward_range(self.work, self.flat, self.grads, self.sflat, ext, begin, end, i == 0,
+                                             stream=stream)
+                    pending.append(self.coll.all_reduce_sum_async(self.grads[lo:hi]))
         except L.VaeAmdError:
             if self._hook_error is not None:
                 e, self._hook_error = self._hook_error, None
@@ -128,7 +148,9 @@ class DataParallelTrainStep(FusedTrainStep):
             raise
         finally:
             lib.vae_set_collective(ctypes.cast(None, L.ALLGATHER_FN), None, 0, 1)
-        self.coll.all_reduce_sum(self.grads)
+        for h in pending:
+            if h is not None:
+                h.wait()
         self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream)
 
     def global_loss(self):

@@ -255,6 +255,35 @@ class CompiledProgram:
                                          stream if stream is not None else L.stream_ptr()),
                 "vae_run_backward")
 
+    def backward_range(self, work, params, grads, state, ext, begin, end, zero_grads, stream=None):
+        """Backward over ops[begin:end) only (vae_run_backward_range): the data-parallel step's gradient buckets."""
+        self._bind(work, params, grads, state, ext)
+        L.check(L.lib().vae_run_backward_range(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                               stream if stream is not None else L.stream_ptr(), begin, end,
+                                               1 if zero_grads else 0),
+                "vae_run_backward_range")
+
+    def grad_buckets(self):
+        """Splits the program at its REPARAM op into (decoder + loss, encoder) ranges and returns
+        [(op_begin, op_end, grad_lo, grad_hi), ...] in backward order, or None when the parameter ranges of the two
+        halves interleave in the flat buffer (then the whole gradient is one bucket)."""
+        ks = [i for i in range(self.n_ops) if self.ops[i].kind == L.OP_REPARAM]
+        if len(ks) != 1:
+            return None
+        k = ks[0]
+
+        def span(lo, hi):
+            offs = []
+            for i in range(lo, hi):
+                op = self.ops[i]
+                if op.kind in (L.OP_CONV, L.OP_CONVT, L.OP_LINEAR, L.OP_BN):
+                    offs += [(r & ((1 << 56) - 1)) for r in (op.r[4], op.r[5]) if r >= 0]
+            return (min(offs), max(offs)) if offs else None
+        dec, enc = span(k + 1, self.n_ops), span(0, k + 1)
+        if dec is None or enc is None or not (enc[1] < dec[0]):
+            return None
+        return [(k + 1, self.n_ops, dec[0], None), (0, k + 1, 0, dec[0])]
+
     def view(self, work, buf, shape=None):
         """Tensor view of a dense WORK buffer ([B][buf.n]); shape = per-sample shape."""
         assert (buf.ref >> 56) == L.SP_WORK and buf.ld == buf.n
