@@ -22,6 +22,7 @@ GEOMS = [
     (32, 3, 3, 16, 3, 3, 2, 0, True, 0, 45),
     (16, 7, 7, 8, 3, 3, 2, 1, True, 1, 23),
     (8, 14, 14, 1, 3, 3, 2, 1, True, 1, 37),        # 1 output channel: vector-ALU variant
+    (32, 14, 14, 1, 3, 3, 2, 1, True, 1, 29),       # 1 output channel, long K: still the vector-ALU variant
     (18, 1, 1, 12, 1, 2, 2, 0, True, 0, 64),        # TCVAE decoder ConvT1d k2 s2
     (6, 1, 4, 3, 1, 2, 2, 0, True, 0, 70),
     (7, 5, 4, 9, 4, 3, 2, 1, True, 0, 12),
