@@ -471,7 +471,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // element happen per WORKGROUP, not per chunk.  The bias gradient is the per-channel sum of the
 // d(pre-activation) tensor, taken from its LDS image (a zero halo adds nothing).
 #define WG_MAXT 20
-#define WG_SMALL_T 2  // kernels with at most this many accumulator tiles fit 128 VGPRs: two workgroups per CU
+#define WG_SMALL_T 4  // kernels with at most this many accumulator tiles run at two workgroups per CU (<= 128 VGPRs; the 2x2 instance spills 31 registers there and is still faster than one workgroup per CU)
 
 struct WgArgs {
     TensorIn S, G;
