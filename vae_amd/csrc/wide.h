@@ -19,9 +19,6 @@
 #define WD_THREADS 256
 #define WD_ST 17  // LDS row stride (floats)
 
-// exact n / d for 0 <= n < 2^20 and small d through the float reciprocal (inv = 1.f / d)
-__device__ __forceinline__ int wd_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
-
 __device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, int arow0, int brow0, int li, int lk,
                                              f32x4 (&acc)[2][2]) {
 #pragma unroll
