@@ -242,13 +242,10 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             pre_load(a.in, (int64_t)blockIdx.x * a.SB * CHW, (uint32_t)(min(a.SB, a.B - (int)blockIdx.x * a.SB) * CHW),
                      pr);
     }
-    // ---- once per workgroup: clear the input image (the halo must read as zero and is never
-    // written again), build the tap-offset tables and the [k][n] weight images of every class
-    for (int i = tid; i < a.lds_in; i += IG_THREADS) lin[i] = 0.f;
-    ig_load_coef(a.in.coef, cin, 8 * g.Cin);
-    ig_load_coef(a.ep_coef, cep, 8 * g.N);
-    for (int i = tid; i < g.Np; i += IG_THREADS) lbias[i] = (a.bias != nullptr && i < g.N) ? a.bias[i] : 0.f;
+    // ---- once per workgroup (igemm_tables.inc): clear the input image, load the coefficient blocks and the bias,
+    // build the pixel table, the tap-offset tables and the [k][n] weight images of every class
     float* const dummy = lbias + g.Np;  // spare LDS word: masked-off epilogue stores land here
+    int* const wbase = reinterpret_cast<int*>(lbias + g.Np + 8);  // [lds_tab] weight base index per reduction row (set-up only)
     if (a.ncls > 1) {
 #define MULTI 1
 #include "igemm_tables.inc"

@@ -434,6 +434,14 @@ static int fill_classes(const IgGeom& g, IgClass* cls, int* wsum, int* tsum) {
     *wsum = woff; *tsum = toff;
     return ncls;
 }
+// The kernel's time is that of the workgroup with the most chunks: with `rounds` = chunks per workgroup fixed by
+// the largest feasible chunk, the smallest chunk that still needs only that many rounds wastes the least
+// (B = 4096, 512 workgroups, 5 samples fit: 820 chunks = 2 rounds of 5; 4 samples = 1024 chunks = 2 rounds of 4).
+static int balanced_chunk(int B, int sb, int grid) {
+    const int64_t chunks = ceil_div64(B, sb), rounds = ceil_div64(chunks, grid);
+    const int bal = (int)ceil_div64(B, (int64_t)grid * rounds);
+    return bal < sb ? (bal < 1 ? 1 : bal) : sb;
+}
 // LDS need of the gather kernel for SB samples per chunk; picks SB for batch B (0 if it cannot fit)
 static IgPlan plan_gather(const IgGeom& g, int B) {
     IgPlan p;
@@ -443,7 +451,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
     fill_classes(g, cls, &wsum, &tsum);
     const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW + g.OH * g.OW;  // (+ pixel table)
-    const int coef = 8 * (g.Cin + g.N) + g.Np + 8;
+    const int coef = 8 * (g.Cin + g.N) + g.Np + 8 + tsum;  // (+ the set-up's weight-base table, one int per tap-table row)
     const int fixed = wsum + tsum + coef;
     int fit = (IG_LDS_BUDGET_FLOATS - fixed - 4) / (per_in + per_out);
     if (fit > 64) fit = 64;
@@ -457,6 +465,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
         const int cap = IG_PRE * IG_THREADS / (g.Cin * g.H * g.W);
         p.pre = cap >= 1;
         if (p.pre && sb > cap) sb = cap;
+        sb = balanced_chunk(B, sb, IG_MAX_GRID);
     }
     p.SB = sb;
     p.lds_in = (sb * per_in + 3) & ~3;  // keeps the weight image behind it 16-byte aligned
@@ -507,6 +516,7 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
         const int cap = WG_PRE * IG_THREADS / big;
         p.pre = cap >= 1 && sb >= 1;
         if (p.pre && sb > cap) sb = cap;
+        if (sb >= 1) sb = balanced_chunk(B, sb, T <= WG_SMALL_T ? IG_WG_MAX_GRID : IG_WG_MAX_GRID / 2);
     }
     p.SB = sb;
     p.lds_S = sb * per_S; p.lds_G = sb * per_G;
