@@ -404,10 +404,34 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
         const int64_t obase = (int64_t)s0 * g.N * OHW;
         const int total = sb * g.N * OHW;
-        if (a.slab == nullptr && a.ep_mode == EP_PLAIN) {
+        if (a.ep_mode == EP_PLAIN) {
             // (the activation runs here, once per real output element with every lane busy, not in the
             // MFMA epilogue where 15 of 16 lanes may hold padding channels)
             for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
+            if (a.slab == nullptr) continue;
+            // BatchNorm statistics from the LDS image, one wave per channel (no global traffic in this loop):
+            // sums stay in registers and are reduced once; no atomics, fixed order => deterministic
+            for (int n = wid; n < g.N; n += IG_WAVES) {
+                const float pv = act_apply(lout[n * OHW], a.act, a.slope);  // chunk-local pivot: the channel's first value
+                float s1 = 0.f, s2 = 0.f;
+                for (int s = 0; s < sb; ++s) {
+                    const int rbase = (s * g.N + n) * OHW;
+                    for (int i = lane; i < OHW; i += 64) {
+                        const float d = act_apply(lout[rbase + i], a.act, a.slope) - pv;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
+                    sl[0] = pv;
+                    sl[1] = s1;
+                    sl[2] = s2;
+                    sl[3] = (float)(sb * OHW);
+                }
+            }
             continue;
         }
         // one wave per channel: it walks that channel's row in every sample of the chunk, so the two
