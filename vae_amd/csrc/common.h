@@ -28,17 +28,23 @@ void vae_set_error(const char* fmt, ...);
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers ----------------------------------------------------------------------
+// Wave-wide sum on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts): six vector
+// instructions, where a __shfl_down tree is six dependent ds_bpermute round trips through the LDS crossbar
+// (~1 us for the handful of sums an epilogue takes).  Fixed order => deterministic.  Valid in EVERY lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, VAE_WAVE);
-    return v;  // valid in lane 0
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1  (lanes without a source add 0)
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-
-__device__ __forceinline__ float wave_sum_all(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, VAE_WAVE);
-    return v;  // valid in every lane
-}
+__device__ __forceinline__ float wave_sum_all(float v) { return wave_sum(v); }
 
 // Sum over a 256-thread block; result valid in thread 0.  `sm` >= 4 floats of LDS.
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
