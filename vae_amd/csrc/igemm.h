@@ -110,7 +110,10 @@ struct IgArgs {
 #define IG_WAVES (IG_THREADS / 64)
 #define IG_UNROLL 8
 #define IG_PRE 16     // gather: prefetch registers per lane
-#define WG_PRE 8      // wgrad: per tensor
+#define WG_PRE 8      // wgrad: per tensor ...
+// ... and 16 for the instances with 5-10 accumulator tiles: they run one workgroup per CU with a 256-register budget
+// and were held to 2-sample chunks (8 rounds per workgroup, each paying the staging latency) by 8 registers
+#define WG_PRE_OF(T) ((T) > WG_SMALL_T && (T) <= 10 ? 16 : WG_PRE)
 
 // Stage [sb][C][H][W] (global, contiguous) into the padded LDS image, applying the transform.
 // IG_UNROLL independent elements per lane and iteration: all their global loads are in flight
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
 
     // the first chunk's loads are issued before anything else: the set-up below hides their latency
     const int SCHW = a.Sc * SHW, GCHW = a.Gc * a.GH * a.GW;
-    PreRegs<WG_PRE, true> pS, pG;
+    PreRegs<WG_PRE_OF(MT * NT), true> pS, pG;
     if (a.pre) {
         pre_decode(pS, (uint32_t)(a.SB * SCHW), a.Sc, SHW, a.SW, a.SH, a.SW, 0, 0, a.dS_CHW, a.dS_HW, a.dS_W);
         pre_decode(pG, (uint32_t)(a.SB * GCHW), a.Gc, a.GH * a.GW, a.GW, a.Hp, a.Wp, a.ph, a.pw, a.dG_CHW, a.dG_HW,

@@ -513,7 +513,7 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
         if (sb * (per_S + per_G) < T * 256 && (B >= fit)) sb = 0;
         // register prefetch of the next chunk: WG_PRE registers per lane and tensor
         const int big = per_S > Gc * GH * GW ? per_S : Gc * GH * GW;
-        const int cap = WG_PRE * IG_THREADS / big;
+        const int cap = WG_PRE_OF(T) * IG_THREADS / big;
         p.pre = cap >= 1 && sb >= 1;
         if (p.pre && sb > cap) sb = cap;
         if (sb >= 1) sb = balanced_chunk(B, sb, T <= WG_SMALL_T ? IG_WG_MAX_GRID : IG_WG_MAX_GRID / 2);
