@@ -437,49 +437,40 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
             continue;
         }
-        // one wave per channel: it walks that channel's row in every sample of the chunk, so the two
-        // sums stay in registers and are reduced once; no atomics, fixed order => deterministic
+        // EP_BNGRAD (backward through the producer's virtual BatchNorm): one wave per channel walks that channel's
+        // row in every sample of the chunk, so the two sums stay in registers and are reduced once; no atomics,
+        // fixed order => deterministic.  The producer outputs y come from global memory: the loads of eight row
+        // segments are issued together (one at a time, each exposed its full latency: 3-5 us per chunk).
+        const int nI = (OHW + 63) >> 6, nIt = sb * nI;
         for (int n = wid; n < g.N; n += IG_WAVES) {
-            float s1 = 0.f, s2 = 0.f, pv = 0.f, mean = 0.f, rstd = 0.f, sc = 0.f, sh = 0.f;
-            if (a.ep_mode == EP_BNGRAD) {
-                mean = cep[n];
-                rstd = cep[g.N + n];
-                sc = cep[2 * g.N + n];
-                sh = cep[3 * g.N + n];
-            } else {
-                pv = act_apply(lout[n * OHW], a.act, a.slope);  // chunk-local pivot: the channel's first value
-            }
-            for (int s = 0; s < sb; ++s) {
-                const int rbase = (s * g.N + n) * OHW;
-                for (int i = lane; i < OHW; i += 64) {
-                    float v = act_apply(lout[rbase + i], a.act, a.slope);
-                    if (a.ep_mode == EP_BNGRAD) {
-                        const float y = a.ep_y[obase + rbase + i];
-                        if (a.ep_relu && fmaf(y - mean, sc, sh) <= 0.f) v = 0.f;
-                        s1 += v;
-                        s2 = fmaf(v, (y - mean) * rstd, s2);
-                    } else {
-                        const float d = v - pv;
-                        s1 += d;
-                        s2 = fmaf(d, d, s2);
-                    }
-                    a.out[obase + rbase + i] = v;
+            const float mean = cep[n], rstd = cep[g.N + n], sc = cep[2 * g.N + n], sh = cep[3 * g.N + n];
+            float s1 = 0.f, s2 = 0.f;
+            for (int it0 = 0; it0 < nIt; it0 += 8) {
+                float yv[8];
+                int off[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = it0 + u, s = it / nI, i = (it - s * nI) * 64 + lane;
+                    off[u] = (it < nIt && i < OHW) ? (s * g.N + n) * OHW + i : -1;
+                    yv[u] = off[u] >= 0 ? a.ep_y[obase + off[u]] : 0.f;
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (off[u] >= 0) {
+                        float v = act_apply(lout[off[u]], a.act, a.slope);
+                        if (a.ep_relu && fmaf(yv[u] - mean, sc, sh) <= 0.f) v = 0.f;
+                        s1 += v;
+                        s2 = fmaf(v, (yv[u] - mean) * rstd, s2);
+                        a.out[obase + off[u]] = v;
+                    }
             }
             if (a.slab != nullptr) {
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
                 if (lane == 0) {
                     float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
-                    if (a.ep_mode == EP_BNGRAD) {
-                        sl[0] = s1;
-                        sl[1] = s2;
-                    } else {
-                        sl[0] = pv;
-                        sl[1] = s1;
-                        sl[2] = s2;
-                        sl[3] = (float)(sb * OHW);
-                    }
+                    sl[0] = s1;
+                    sl[1] = s2;
                 }
             }
         }
