@@ -296,3 +296,35 @@ def test_train_epoch_from_device_windows():
     avg1 = train(model, loader, criterion, opt, DEV, 1)
     avg2 = train(model, loader, criterion, opt, DEV, 2)
     assert avg1 == avg1 and avg2 < avg1, (avg1, avg2)      # finite, and the ELBO goes down
+
+
+@pytest.mark.parametrize("family", ["mnist", "multiscale"])
+def test_backward_in_gradient_buckets_equals_one_pass(family):
+    """vae_run_backward_range over the data-parallel step's two buckets (decoder + loss ops, then encoder ops)
+    leaves the same GRAD buffer as one vae_run_backward."""
+    import vae_amd
+    from vae_amd.train import FusedTrainStep
+    torch.manual_seed(3)
+    if family == "mnist":
+        model, x = vae_amd.mnist_vae.VariationalAutoencoder(15), torch.rand(200, 1, 28, 28)
+    else:
+        model, x = vae_amd.multiscale_vae.vae(3, 60, 15), 50 + 10 * torch.randn(200, 3, 60)
+    model = model.to(DEV).train()
+    st = FusedTrainStep(model, vae_amd.optim.Adam(model.parameters(), lr=1e-3), 200, DEV, use_graph=False)
+    st.inject_eps = True
+    st.x.copy_(x.to(DEV))
+    st.eps.copy_(torch.randn(st.eps.shape, generator=torch.Generator().manual_seed(4)).to(DEV))
+    ext = [st.x.view(200, -1), st.eps]
+    buckets = st.prog.grad_buckets()
+    assert buckets is not None
+    st.prog.forward(st.work, st.flat, st.sflat, ext, True)
+    st.prog.backward(st.work, st.flat, st.grads, st.sflat, ext)
+    whole = st.grads.clone()
+    st.grads.fill_(7.0)                                          # the first range must clear the buffer
+    st.prog.forward(st.work, st.flat, st.sflat, ext, True)
+    for i, (begin, end, lo, hi) in enumerate(buckets):
+        st.prog.backward_range(st.work, st.flat, st.grads, st.sflat, ext, begin, end, i == 0)
+        if i == 0:                                               # the decoder's bucket is complete after its range
+            torch.testing.assert_close(st.grads[lo:hi], whole[lo:hi], rtol=1e-4, atol=1e-5 * float(whole.abs().max()))
+    torch.testing.assert_close(st.grads, whole, rtol=1e-4, atol=1e-5 * float(whole.abs().max()))
+    assert float(whole.abs().max()) > 0
