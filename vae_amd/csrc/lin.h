@@ -34,6 +34,18 @@ struct LinArgs {
     int a_act, act, accumulate;
     float a_slope, slope;
     FastDiv d_KC, d_KC4;  // by KC and by KC/4
+    // Two Linear layers that read the same input run as one launch:
+    //  forward  - a second head (W2, bias2, C2, N2, ldc2) takes the column blocks blockIdx.y >= ny1 (0: no second head);
+    //  backward - the input gradient sums both layers: a second K segment (Ab, A2b, Wb; same K, lda, lda2, strides)
+    //             is walked after the first (nseg = 2).
+    const float* W2;
+    const float* bias2;
+    float* C2;
+    int N2, ldc2, ny1;
+    const float* Ab;
+    const float* A2b;
+    const float* Wb;
+    int nseg;
 };
 
 // VEC: rows are 16-byte aligned and K, N are multiples of 4 where it matters (host-checked), so the tile
@@ -45,7 +57,13 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
     float* Ws = As + LIN_BM * a.Kp;    // [KC][33]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int m0 = blockIdx.x * LIN_BM, n0 = blockIdx.y * LIN_BN;
+    // (second forward head: its own weights, bias and output)
+    const bool head2 = a.ny1 > 0 && (int)blockIdx.y >= a.ny1;
+    const float* const Wh = head2 ? a.W2 : a.W;
+    const float* const biash = head2 ? a.bias2 : a.bias;
+    float* const Ch = head2 ? a.C2 : a.C;
+    const int Nh = head2 ? a.N2 : a.N, ldch = head2 ? a.ldc2 : a.ldc;
+    const int m0 = blockIdx.x * LIN_BM, n0 = (head2 ? blockIdx.y - a.ny1 : blockIdx.y) * LIN_BN;
 
     const int mt = wid >> 1, nt = wid & 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -53,8 +71,12 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
     const float* wp = Ws + lk * LIN_WS + nt * 16 + li;
     const int total = LIN_BM * a.KC;  // == LIN_BN * a.KC
     const bool nfast = (a.wsn == 1);
+    for (int seg = 0; seg < a.nseg; ++seg) {
+    const float* const Ag = seg ? a.Ab : a.A;
+    const float* const A2g = seg ? a.A2b : a.A2;
+    const float* const Wg = seg ? a.Wb : Wh;
     for (int kc0 = 0; kc0 < a.K; kc0 += a.KC) {
-        if (kc0 > 0) __syncthreads();
+        if (kc0 > 0 || seg > 0) __syncthreads();
         if (VEC) {
             const int total4 = total >> 2;  // groups of 4 consecutive k (A, W[n][k]) or n (W[k][n])
             constexpr int U = 5;
@@ -68,13 +90,13 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
                     if (e < total4) {
                         const int r = fdiv((uint32_t)e, a.d_KC4), k = (e - r * (a.KC >> 2)) << 2;
                         if (m0 + r < a.B && kc0 + k < a.K) {
-                            va[j] = *reinterpret_cast<const float4*>(a.A + (int64_t)(m0 + r) * a.lda + kc0 + k);
-                            if (a.A2 != nullptr)
-                                vy[j] = *reinterpret_cast<const float4*>(a.A2 + (int64_t)(m0 + r) * a.lda2 + kc0 + k);
+                            va[j] = *reinterpret_cast<const float4*>(Ag + (int64_t)(m0 + r) * a.lda + kc0 + k);
+                            if (A2g != nullptr)
+                                vy[j] = *reinterpret_cast<const float4*>(A2g + (int64_t)(m0 + r) * a.lda2 + kc0 + k);
                         }
                         const int wn = nfast ? (e & 7) << 2 : r, wk = nfast ? (e >> 3) : k;
-                        if (n0 + wn < a.N && kc0 + wk < a.K)
-                            vw[j] = *reinterpret_cast<const float4*>(a.W + (int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn);
+                        if (n0 + wn < Nh && kc0 + wk < a.K)
+                            vw[j] = *reinterpret_cast<const float4*>(Wg + (int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn);
                     }
                 }
 #pragma unroll
@@ -82,7 +104,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
                     const int e = base + j * LIN_THREADS;
                     if (e < total4) {
                         const int r = fdiv((uint32_t)e, a.d_KC4), k = (e - r * (a.KC >> 2)) << 2;
-                        if (a.A2 != nullptr) {
+                        if (A2g != nullptr) {
                             va[j].x *= act_grad_from_out(vy[j].x, a.a_act, a.a_slope);
                             va[j].y *= act_grad_from_out(vy[j].y, a.a_act, a.a_slope);
                             va[j].z *= act_grad_from_out(vy[j].z, a.a_act, a.a_slope);
@@ -111,13 +133,13 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
                 if (e < total) {
                     const int r = fdiv((uint32_t)e, a.d_KC), k = e - r * a.KC;
                     if (m0 + r < a.B && kc0 + k < a.K) {
-                        va[j] = a.A[(int64_t)(m0 + r) * a.lda + kc0 + k];
-                        if (a.A2 != nullptr)
-                            va[j] *= act_grad_from_out(a.A2[(int64_t)(m0 + r) * a.lda2 + kc0 + k], a.a_act, a.a_slope);
+                        va[j] = Ag[(int64_t)(m0 + r) * a.lda + kc0 + k];
+                        if (A2g != nullptr)
+                            va[j] *= act_grad_from_out(A2g[(int64_t)(m0 + r) * a.lda2 + kc0 + k], a.a_act, a.a_slope);
                     }
                     // weight tile: walk the memory-contiguous index fastest
                     const int wn = nfast ? (e & 31) : r, wk = nfast ? (e >> 5) : k;
-                    if (n0 + wn < a.N && kc0 + wk < a.K) vw[j] = a.W[(int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn];
+                    if (n0 + wn < Nh && kc0 + wk < a.K) vw[j] = Wg[(int64_t)(kc0 + wk) * a.wsk + (int64_t)(n0 + wn) * a.wsn];
                 }
             }
 #pragma unroll
@@ -142,16 +164,17 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
         }
     }
+    }
     // D: col = li, row = lk*4 + r
     const int n = n0 + nt * 16 + li;
-    if (n >= a.N) return;
-    const float bv = a.bias != nullptr ? a.bias[n] : 0.f;
+    if (n >= Nh) return;
+    const float bv = biash != nullptr ? biash[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + lk * 4 + r;
         if (m < a.B) {
             float v = act_apply(acc[r] + bv, a.act, a.slope);
-            float* cp = a.C + (int64_t)m * a.ldc + n;
+            float* cp = Ch + (int64_t)m * ldch + n;
             *cp = a.accumulate ? *cp + v : v;
         }
     }

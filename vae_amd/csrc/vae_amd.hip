@@ -1007,8 +1007,17 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     if (a.A2 != nullptr) vec = vec && a.lda2 % 4 == 0 && al16(a.A2);
     if (a.wsn == 1) vec = vec && a.wsk % 4 == 0 && a.N % 4 == 0;  // W'[k][n], n contiguous
     else vec = vec && a.wsn % 4 == 0 && a.wsk == 1;               // W'[n][k], k contiguous
+    if (a.nseg < 1) a.nseg = 1;
+    if (a.nseg == 2) vec = vec && al16(a.Ab) && al16(a.Wb) && (a.A2b == nullptr || al16(a.A2b));
+    int ny = (a.N + LIN_BN - 1) / LIN_BN;
+    a.ny1 = 0;
+    if (a.W2 != nullptr) {  // second forward head
+        vec = vec && al16(a.W2) && (a.wsn != 1 || a.N2 % 4 == 0);
+        a.ny1 = ny;
+        ny += (a.N2 + LIN_BN - 1) / LIN_BN;
+    }
     const size_t bytes = (size_t)(LIN_BM * a.Kp + a.KC * LIN_WS) * sizeof(float);
-    dim3 grid((a.B + LIN_BM - 1) / LIN_BM, (a.N + LIN_BN - 1) / LIN_BN);
+    dim3 grid((a.B + LIN_BM - 1) / LIN_BM, ny);
     if (vec) hipLaunchKernelGGL(lin_fwd_k<true>, grid, dim3(LIN_THREADS), bytes, c.s, a);
     else hipLaunchKernelGGL(lin_fwd_k<false>, grid, dim3(LIN_THREADS), bytes, c.s, a);
     VAE_LAUNCH_CHECK(what);
@@ -1038,9 +1047,23 @@ static int linear_check(const Ctx& c, const vae_op& op) {
 }
 static inline int64_t strided_extent(int B, int ld, int n) { return (int64_t)(B - 1) * ld + n; }
 
-static int linear_forward(const Ctx& c, const vae_op& op) {
+// Two adjacent LINEAR ops that read the same input with the same shape of it (the mu / logvar heads, the two
+// 288 -> 100 branches of the notebook encoder) run as one launch, forward (two heads) and in the input gradient
+// (two K segments): every launch saved is >= 4.6 us of a step that is bound by them.
+static bool linear_siblings(const vae_op& p, const vae_op& q) {
+    return p.kind == VAE_OP_LINEAR && q.kind == VAE_OP_LINEAR && p.r[0] == q.r[0] && p.d[0] == q.d[0] &&
+           p.d[2] == q.d[2] && p.act == q.act && p.f[0] == q.f[0];
+}
+// (input gradient: also the same destination and leading dimensions, and equally wide outputs)
+static bool linear_dgrad_siblings(const vae_op& p, const vae_op& q) {
+    return linear_siblings(p, q) && p.r[2] >= 0 && p.r[2] == q.r[2] && p.d[4] == q.d[4] && p.d[1] == q.d[1] &&
+           p.d[3] == q.d[3] && p.d[5] == q.d[5];
+}
+
+static int linear_forward(const Ctx& c, const vae_op& op, const vae_op* sib = nullptr) {
     int rc = linear_check(c, op);
     if (rc) return rc;
+    if (sib != nullptr && (rc = linear_check(c, *sib)) != VAE_OK) return rc;
     const int K = op.d[0], N = op.d[1], ldx = op.d[2], ldy = op.d[3];
     bool ok = true;
     LinArgs a;
@@ -1053,10 +1076,19 @@ static int linear_forward(const Ctx& c, const vae_op& op) {
     a.B = c.B; a.N = N; a.K = K;
     a.lda = ldx; a.ldc = ldy; a.wsk = 1; a.wsn = K;
     a.act = op.act; a.slope = op.f[0];
+    if (sib != nullptr) {
+        a.N2 = sib->d[1]; a.ldc2 = sib->d[3];
+        a.C2 = resolve(c, sib->r[1], strided_extent(c.B, a.ldc2, a.N2), "linear.out", &ok);
+        a.W2 = resolve(c, sib->r[4], (int64_t)a.N2 * K, "linear.w", &ok);
+        a.bias2 = resolve_opt(c, sib->r[5], a.N2, "linear.b", &ok);
+        if (!ok) return VAE_EINVAL;
+    }
     return launch_lin(c, a, "lin_fwd_k(fwd)");
 }
 
-static int linear_backward(const Ctx& c, const vae_op& op) {
+// sib: the sibling processed just before (the later op of the pair), whose input gradient was left to this call;
+// skip_dgrad: this op IS that later op.
+static int linear_backward(const Ctx& c, const vae_op& op, const vae_op* sib = nullptr, bool skip_dgrad = false) {
     int rc = linear_check(c, op);
     if (rc) return rc;
     const int K = op.d[0], N = op.d[1], ldx = op.d[2], ldy = op.d[3], lddx = op.d[4], lddy = op.d[5];
@@ -1091,7 +1123,7 @@ static int linear_backward(const Ctx& c, const vae_op& op) {
     }
     c.lin_wg.l[c.lin_wg.n++] = wa;
     // 2) dX[B][K] (=|+=) (dY*act') W
-    if (dx != nullptr) {
+    if (dx != nullptr && !skip_dgrad) {
         LinArgs b;
         memset(&b, 0, sizeof(b));
         b.A = dy; b.lda = lddy;
@@ -1100,6 +1132,14 @@ static int linear_backward(const Ctx& c, const vae_op& op) {
         b.C = dx; b.ldc = lddx;
         b.B = c.B; b.N = K; b.K = N;
         b.accumulate = (op.flags & VAE_F_ACC_DIN) ? 1 : 0;
+        if (sib != nullptr) {  // + (dY_sib*act') W_sib as a second K segment; the pair's first write decides = or +=
+            b.nseg = 2;
+            b.Ab = resolve(c, sib->r[3], strided_extent(c.B, lddy, N), "linear.dout", &ok);
+            b.A2b = op.act != VAE_ACT_NONE ? resolve(c, sib->r[1], strided_extent(c.B, ldy, N), "linear.out", &ok) : nullptr;
+            b.Wb = resolve(c, sib->r[4], (int64_t)N * K, "linear.w", &ok);
+            if (!ok) return VAE_EINVAL;
+            b.accumulate = (sib->flags & VAE_F_ACC_DIN) ? 1 : 0;
+        }
         rc = launch_lin(c, b, "lin_fwd_k(dgrad)");
     }
     return rc;
@@ -1238,7 +1278,14 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
                                int n_bases, int B, int training, vae_stream_t stream) {
     Ctx c;
     int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
-    for (int i = 0; i < n_ops && rc == VAE_OK; ++i) rc = forward_op(c, ops[i], i, training);
+    for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
+        if (i + 1 < n_ops && linear_siblings(ops[i], ops[i + 1])) {
+            rc = linear_forward(c, ops[i], &ops[i + 1]);
+            ++i;
+        } else {
+            rc = forward_op(c, ops[i], i, training);
+        }
+    }
     return rc;
 }
 
@@ -1285,7 +1332,15 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
             case VAE_OP_CONV:
             case VAE_OP_CONVT: rc = (op.flags & VAE_F_FUSED) ? conv_backward_fused(c, op) : conv_backward(c, op); break;
             case VAE_OP_BN: rc = (op.flags & VAE_F_FUSED) ? bn_virtual_backward(c, op) : bn_backward(c, op); break;
-            case VAE_OP_LINEAR: rc = linear_backward(c, op); break;
+            case VAE_OP_LINEAR:
+                if (i - 1 >= op_begin && linear_dgrad_siblings(ops[i - 1], op)) {
+                    rc = linear_backward(c, op, nullptr, true);                   // weight gradient only
+                    if (rc == VAE_OK) rc = linear_backward(c, ops[i - 1], &op);   // + the pair's input gradient
+                    --i;
+                } else {
+                    rc = linear_backward(c, op);
+                }
+                break;
             case VAE_OP_REPARAM: rc = reparam_backward(c, op); break;
             case VAE_OP_SLICE0: rc = slice0_backward(c, op); break;
             case VAE_OP_ELBO: rc = elbo_backward(c, op); break;

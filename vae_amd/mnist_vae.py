@@ -33,12 +33,13 @@ class VariationalEncoder(HipModule):
         h = b.batchnorm(h, cnn[3], c1, hw[0] * hw[1], relu=True)
         h, hw = b.conv(h, cnn[5].weight, cnn[5].bias, c1, hw, c2, (3, 3), (2, 2), (0, 0), act=L.ACT_LEAKY)
         K = c2 * hw[0] * hw[1]
-        # both heads read h: the std head (emitted last) runs first in backward and stores d(h)
-        t = b.linear(h, self.encoder_mean[0].weight, self.encoder_mean[0].bias, K, self.hidden, act=L.ACT_LEAKY,
-                     acc_din=True)
-        b.linear(t, self.encoder_mean[2].weight, self.encoder_mean[2].bias, self.hidden, self.latent_dims, out=mu_out)
-        t = b.linear(h, self.encoder_std[0].weight, self.encoder_std[0].bias, K, self.hidden, act=L.ACT_LEAKY)
-        b.linear(t, self.encoder_std[2].weight, self.encoder_std[2].bias, self.hidden, self.latent_dims, out=logvar_out)
+        # both branches read h: the std branch (emitted second) runs first in backward and stores d(h); their first
+        # layers are emitted next to each other so that the executor runs the pair as one launch (forward and d(h))
+        tm = b.linear(h, self.encoder_mean[0].weight, self.encoder_mean[0].bias, K, self.hidden, act=L.ACT_LEAKY,
+                      acc_din=True)
+        ts = b.linear(h, self.encoder_std[0].weight, self.encoder_std[0].bias, K, self.hidden, act=L.ACT_LEAKY)
+        b.linear(tm, self.encoder_mean[2].weight, self.encoder_mean[2].bias, self.hidden, self.latent_dims, out=mu_out)
+        b.linear(ts, self.encoder_std[2].weight, self.encoder_std[2].bias, self.hidden, self.latent_dims, out=logvar_out)
 
     def emit_program(self, b, training):
         x = b.input("x", 784)
