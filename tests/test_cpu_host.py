@@ -126,3 +126,46 @@ def test_gradient_buckets_split_at_the_reparameterisation():
         assert e0 == prog.n_ops and b0 == e1 and b1 == 0          # backward order, every op exactly once
         first_dec = min(o for n, o in names if n.startswith("decoder"))
         assert lo0 == first_dec and hi0 is None and (lo1, hi1) == (0, first_dec), (stem, buckets, first_dec)
+
+
+def test_c_abi_rejects_bad_programs_before_any_launch():
+    """Host-side validation of the executor (no GPU needed: every check precedes the first HIP call):
+    null arguments, batch out of range, unknown op kind, inconsistent conv geometry, references outside the
+    bound address spaces.  Each returns VAE_EINVAL (-1) and leaves a message in vae_last_error()."""
+    import ctypes
+    from vae_amd import _lib as L
+    lib = L.lib()
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    fake = (ctypes.c_float * 64)()                      # host memory: only its ADDRESS is used, nothing is launched
+    bases = (vp * 4)(ctypes.addressof(fake), ctypes.addressof(fake), ctypes.addressof(fake), ctypes.addressof(fake))
+    sizes = (i64 * 4)(64, 64, 64, 64)
+
+    def run(ops, n, B=8, n_bases=4):
+        rc = lib.vae_run_forward(ops, n, bases, sizes, n_bases, B, 1, None)
+        return rc, lib.vae_last_error().decode()
+
+    ops = (L.VaeOp * 1)()
+    assert run(ops, 1, B=0) == (-1, "batch 0 out of range")
+    assert run(ops, 1, n_bases=2)[0] == -1 and "n_bases" in lib.vae_last_error().decode()
+    ops[0].kind = 99
+    rc, msg = run(ops, 1)
+    assert rc == -1 and "unknown kind 99" in msg
+    # conv whose output size does not follow from input, kernel, stride and padding
+    ops[0].kind = L.OP_CONV
+    for j, v in enumerate((1, 28, 28, 8, 13, 14, 3, 3, 2, 2, 1, 1)):
+        ops[0].d[j] = v
+    rc, msg = run(ops, 1)
+    assert rc == -1 and "inconsistent" in msg, msg
+    # a Linear whose input extent leaves the WORK space (64 floats bound, 8 x 100 needed)
+    ops[0] = L.VaeOp()
+    ops[0].kind = L.OP_LINEAR
+    for j in range(12):
+        ops[0].r[j] = -1
+    ops[0].r[0], ops[0].r[1], ops[0].r[4] = 0, 0, (L.SP_PARAM << 56)
+    for j, v in enumerate((100, 4, 100, 4, 100, 4)):
+        ops[0].d[j] = v
+    rc, msg = run(ops, 1)
+    assert rc == -1 and "exceeds space" in msg, msg
+    # backward over an op range outside the program
+    rc = lib.vae_run_backward_range(ops, 1, bases, sizes, 4, 8, None, 0, 2, 1)
+    assert rc == -1 and "op range" in lib.vae_last_error().decode()
