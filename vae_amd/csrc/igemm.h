@@ -410,7 +410,18 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (a.ep_mode == EP_PLAIN) {
             // (the activation runs here, once per real output element with every lane busy, not in the
             // MFMA epilogue where 15 of 16 lanes may hold padding channels)
-            for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
+            if (((g.N * OHW) & 3) == 0) {  // chunk start and length are multiples of 4 floats: 16-byte stores
+                const float4* l4 = reinterpret_cast<const float4*>(lout);
+                float4* o4 = reinterpret_cast<float4*>(a.out + obase);
+                for (int e = tid; e < (total >> 2); e += IG_THREADS) {
+                    float4 v = l4[e];
+                    v.x = act_apply(v.x, a.act, a.slope); v.y = act_apply(v.y, a.act, a.slope);
+                    v.z = act_apply(v.z, a.act, a.slope); v.w = act_apply(v.w, a.act, a.slope);
+                    o4[e] = v;
+                }
+            } else {
+                for (int e = tid; e < total; e += IG_THREADS) a.out[obase + e] = act_apply(lout[e], a.act, a.slope);
+            }
             if (a.slab == nullptr) continue;
             // BatchNorm statistics from the LDS image, one wave per channel (no global traffic in this loop):
             // sums stay in registers and are reduced once; no atomics, fixed order => deterministic
