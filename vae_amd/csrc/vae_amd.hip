@@ -1232,7 +1232,7 @@ static int elbo_forward(const Ctx& c, const vae_op& op) {
     return elbo_fwd_impl(c.s, xr, tg, mu, lv, out, part, c.B, nps, op.d[1], op.d[2], latent,
                          (op.flags & VAE_F_BCE) ? 1 : 0, op.d[5]);
 }
-static int elbo_backward(const Ctx& c, const vae_op& op) {
+static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullptr, int64_t zero_n = 0) {
     const int nps = op.d[0], latent = op.d[3];
     bool ok = true;
     const float* xr = resolve(c, op.r[0], (int64_t)c.B * nps, "elbo.x_rec", &ok);
@@ -1243,7 +1243,7 @@ static int elbo_backward(const Ctx& c, const vae_op& op) {
     // KL gradients are folded into the REPARAM op's backward (VAE_F_KL_GRAD)
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid((int64_t)c.B * nps)), dim3(256), 0, c.s, xr, tg, nullptr, nullptr, gs,
                        dxr, nullptr, nullptr, (int64_t)c.B, nps, (int64_t)op.d[1], (int64_t)op.d[2], latent,
-                       (op.flags & VAE_F_BCE) ? 1 : 0);
+                       (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n);
     VAE_LAUNCH_CHECK("elbo_bwd_k");
     return VAE_OK;
 }
@@ -1324,10 +1324,16 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
     if (bases[2] == nullptr) VAE_FAIL(VAE_EINVAL, "backward needs the GRAD space (2) bound");
     if (op_begin < 0 || op_end > n_ops || op_begin > op_end)
         VAE_FAIL(VAE_EINVAL, "backward: op range [%d, %d) outside the program of %d ops", op_begin, op_end, n_ops);
-    // weight gradients accumulate with atomics: start from zero
-    if (zero_grads) VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
+    // weight gradients accumulate with atomics: start from zero (cleared by the ELBO op's kernel when the range ends
+    // with one: it runs first and nothing before it touches the GRAD space)
+    const bool zero_in_elbo = zero_grads && op_end > op_begin && ops[op_end - 1].kind == VAE_OP_ELBO;
+    if (zero_grads && !zero_in_elbo) VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
     for (int i = op_end - 1; i >= op_begin && rc == VAE_OK; --i) {
         const vae_op& op = ops[i];
+        if (zero_in_elbo && i == op_end - 1) {
+            rc = elbo_backward(c, op, bases[2], base_sizes[2]);
+            continue;
+        }
         switch (op.kind) {
             case VAE_OP_CONV:
             case VAE_OP_CONVT: rc = (op.flags & VAE_F_FUSED) ? conv_backward_fused(c, op) : conv_backward(c, op); break;
@@ -1373,7 +1379,8 @@ extern "C" int vae_elbo_backward(const float* x_rec, const float* target, const 
     if (B < 1 || n_per_sample < 1 || latent < 1 || t_sb < 0 || t_se < 0) VAE_FAIL(VAE_EINVAL, "elbo: bad shape");
     const int64_t n = (int64_t)B * (n_per_sample > latent ? n_per_sample : latent);
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x_rec, target, mu, logvar,
-                       gscale, dx_rec, dmu, dlogvar, (int64_t)B, n_per_sample, t_sb, t_se, latent, bce);
+                       gscale, dx_rec, dmu, dlogvar, (int64_t)B, n_per_sample, t_sb, t_se, latent, bce, (float*)nullptr,
+                       (int64_t)0);
     VAE_LAUNCH_CHECK("elbo_bwd_k");
     return VAE_OK;
 }
