@@ -171,11 +171,12 @@ int vae_elbo_backward(const float* x_rec, const float* target, const float* mu, 
                       vae_stream_t stream);
 
 /* Fused flat Adam (torch.optim.Adam defaults semantics; draft_pipe.py:132, notebook :249).
- * tick: device int32 step counter, incremented by the kernel chain (graph-replay safe). */
+ * tick: device int32[4] block {step count t, scratch (workgroups done: keep 0), float 1-b1^t, float 1-b2^t}, zeroed
+ * by the caller before the first step; the kernel works with t+1 and stores it (graph-replay safe). */
 int vae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t* tick, vae_stream_t stream);
 
-/* eps ~ N(0,1): Philox4x32-10 + Box-Muller; rng = device uint64[2] {seed, offset}; offset is
+/* eps ~ N(0,1): Philox4x32-10 + Box-Muller; rng = device uint64[3] {seed, offset, 0 (scratch: keep 0)}; offset is
  * advanced on the device (replaces torch.randn_like at vae.py:17). */
 int vae_randn(float* out, int64_t n, uint64_t* rng, vae_stream_t stream);
 

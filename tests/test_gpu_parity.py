@@ -247,7 +247,7 @@ def test_submodule_calls_and_reparam():
 
 def test_device_randn_moments():
     from vae_amd.vae import device_randn
-    rng = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    rng = torch.tensor([1234, 0, 0], dtype=torch.int64, device=DEV)
     a = device_randn((1 << 20,), rng, DEV)
     b = device_randn((1 << 20,), rng, DEV)
     assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3

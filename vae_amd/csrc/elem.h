@@ -151,22 +151,21 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
 }
 
 // ---- Adam ----------------------------------------------------------------------------------
-// tick[0] = step count t (int32, device).  adam_tick_k bumps it once per optimiser step, so a
-// captured graph replays with the right bias correction.  bc[0] = 1-b1^t, bc[1] = 1-b2^t.
-__global__ void adam_tick_k(int32_t* tick, float* bc, float beta1, float beta2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int t = tick[0] + 1;
-        tick[0] = t;
-        bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
-        bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
-    }
-}
+// tick block (device): {int32 step count t, int32 workgroups done, float 1-b1^t, float 1-b2^t}.  Every workgroup
+// reads t and works with t+1; the last one to finish (a device-scope counter) stores t+1, so a captured graph
+// replays with the right bias correction and the step counter needs no kernel of its own.
 __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                   float beta1, float beta2, float eps,
-                                                   const float* __restrict__ bc) {
-    const float step = lr / bc[0];
-    const float rs2 = rsqrtf(bc[1]);  // torch: denom = sqrt(v)/sqrt(bc2) + eps
+                                                   float beta1, float beta2, float eps, int32_t* tick) {
+    __shared__ float sbc[2];
+    if (threadIdx.x == 0) {
+        const int t = tick[0] + 1;
+        sbc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+        sbc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+    __syncthreads();
+    const float step = lr / sbc[0];
+    const float rs2 = rsqrtf(sbc[1]);  // torch: denom = sqrt(v)/sqrt(bc2) + eps
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
@@ -174,6 +173,15 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const 
         m[i] = mi;
         v[i] = vi;
         p[i] -= step * mi / (sqrtf(vi) * rs2 + eps);
+    }
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&tick[1], 1) == (int)gridDim.x - 1) {  // every other workgroup has read tick[0] long ago
+            float* bc = reinterpret_cast<float*>(tick) + 2;
+            bc[0] = sbc[0];
+            bc[1] = sbc[1];
+            tick[1] = 0;
+            tick[0] += 1;
+        }
     }
 }
 
@@ -187,7 +195,9 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
     c0 = n0;
     c2 = n2;
 }
-__global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t n, const uint64_t* __restrict__ rng) {
+// rng (device): {seed, offset, workgroups done}.  The offset is advanced by the last workgroup to finish (every
+// other one has read it by then), so a draw is one launch.
+__global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t n, uint64_t* __restrict__ rng) {
     const uint64_t seed = rng[0], base = rng[1];
     const int64_t nquad = (n + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
@@ -211,12 +221,15 @@ __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t 
         for (int j = 0; j < 4; ++j)
             if (4 * q + j < n) out[4 * q + j] = v[j];
     }
+    __syncthreads();  // (rng[1] was read by every thread of this workgroup)
+    if (threadIdx.x == 0) {
+        unsigned long long* done = reinterpret_cast<unsigned long long*>(rng + 2);
+        if (atomicAdd(done, 1ull) == (unsigned long long)gridDim.x - 1) {
+            rng[2] = 0;
+            rng[1] = base + (uint64_t)nquad;
+        }
+    }
 }
-// advance the offset after a draw (single lane; vector store)
-__global__ void rng_advance_k(uint64_t* rng, uint64_t nquad) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += nquad;
-}
-
 // ---- sliding windows of a resident series ---------------------------------------------------
 // out[b][c][l] = series[c][starts[b] + l]: slidingWindow.__getitem__ (train.py:25-28) for a whole batch on the
 // device; the DataLoader's collate + host-to-device copy of B*C*L floats becomes a gather from the (C, T) series

@@ -1388,11 +1388,9 @@ extern "C" int vae_elbo_backward(const float* x_rec, const float* target, const 
 extern "C" int vae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t* tick, vae_stream_t stream) {
     if (!p || !g || !m || !v || !tick || n < 1) VAE_FAIL(VAE_EINVAL, "adam: bad argument");
-    float* bc = reinterpret_cast<float*>(tick) + 2;  // tick block: {int32 t, pad, float bc1, float bc2}
-    hipLaunchKernelGGL(adam_tick_k, dim3(1), dim3(64), 0, (hipStream_t)stream, tick, bc, beta1, beta2);
-    VAE_LAUNCH_CHECK("adam_tick_k");
+    // tick block: {int32 t, int32 workgroups done, float bc1, float bc2}; the kernel bumps t itself
     hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, bc);
+                       beta2, eps, tick);
     VAE_LAUNCH_CHECK("adam_step_k");
     return VAE_OK;
 }
@@ -1402,8 +1400,6 @@ extern "C" int vae_randn(float* out, int64_t n, uint64_t* rng, vae_stream_t stre
     const int64_t nquad = (n + 3) / 4;
     hipLaunchKernelGGL(randn_k, dim3(ew_grid(nquad)), dim3(256), 0, (hipStream_t)stream, out, n, rng);
     VAE_LAUNCH_CHECK("randn_k");
-    hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(64), 0, (hipStream_t)stream, rng, (uint64_t)nquad);
-    VAE_LAUNCH_CHECK("rng_advance_k");
     return VAE_OK;
 }
 

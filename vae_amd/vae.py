@@ -52,7 +52,7 @@ class HipVAE(HipModule):
         if rng is None or rng.device != device:
             # seeded from torch's global generator so torch.manual_seed() controls eps
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            rng = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+            rng = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)  # {seed, offset, scratch}
             self.__dict__["_rng"] = rng
         return rng
 
