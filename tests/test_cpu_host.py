@@ -169,3 +169,19 @@ def test_c_abi_rejects_bad_programs_before_any_launch():
     # backward over an op range outside the program
     rc = lib.vae_run_backward_range(ops, 1, bases, sizes, 4, 8, None, 0, 2, 1)
     assert rc == -1 and "op range" in lib.vae_last_error().decode()
+
+
+def test_device_window_loader_has_no_cpu_path():
+    """DeviceSlidingWindow keeps the reference Dataset semantics on the host side (len, .dataset) but its gather is
+    a HIP kernel: on a CPU tensor it raises instead of falling back."""
+    import pytest
+    import vae_amd
+    from vae_amd.train import DeviceSlidingWindow
+    data = torch.arange(3 * 100, dtype=torch.float32).view(3, 100)
+    loader = DeviceSlidingWindow(data, 60, batch_size=16, device="cpu")
+    assert len(loader.dataset) == 40 and len(loader) == 3
+    assert torch.equal(loader.dataset[5], data[:, 5:65])          # the reference Dataset (train.py:25-28)
+    with pytest.raises(vae_amd.VaeAmdError):
+        loader.gather(torch.arange(4))
+    with pytest.raises(ValueError):
+        DeviceSlidingWindow(data[:, :60], 60, device="cpu")       # T must exceed L
