@@ -14,6 +14,7 @@
 //                    gradients (Conv dgrad = transposed gather, ConvT dgrad = conv gather).
 //   igemm_wgrad_k  : weight gradient (K = pixels), bias gradient taken while staging.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -330,11 +331,14 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             // the classes of a transposed gather run side by side: each owns waves [w0, w0 + nw) (host: in proportion
             // to its tiles x K), instead of all eight waves walking the classes one after the other
             if (wid < c.w0 || wid >= c.w0 + c.nw) continue;
-            for (int t0 = wid - c.w0; t0 < ntile; t0 += c.nw * TI) {
-                const float* lp[TI];
-                int outoff[TI];
+            // one pass = TT tiles of this wave in flight; the last pass of a wave may have only one valid tile, and
+            // then runs the single-tile instance instead of spending matrix-pipe time on a masked one
+            auto pass = [&](auto tt_c, const int t0) {
+                constexpr int TT = decltype(tt_c)::value;
+                const float* lp[TT];
+                int outoff[TT];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
+                for (int i = 0; i < TT; ++i) {
                     const int q = (t0 + i * c.nw) * 16 + li;
                     const bool valid = q < P;
                     const uint32_t pe = ptab[c.poff + (valid ? q : 0)];
@@ -343,18 +347,18 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
                 const int* kt = ktab + c.toff + lk;
                 for (int nc = 0; nc < n_ntile; nc += NT) {
-                    f32x4 acc[TI][NT];
+                    f32x4 acc[TT][NT];
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int i = 0; i < TI; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int i = 0; i < TT; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const float* lwc = lw + c.woff + lk * g.Np + nc * 16 + li;
                     // KcPad is a multiple of 16: four independent k-steps per iteration
                     for (int k4 = 0; k4 < c.KcPad; k4 += 16) {
                         const int o0 = kt[k4], o1 = kt[k4 + 4], o2 = kt[k4 + 8], o3 = kt[k4 + 12];
-                        float av[TI][4], bw[NT][4];
+                        float av[TT][4], bw[NT][4];
 #pragma unroll
-                        for (int i = 0; i < TI; ++i) {
+                        for (int i = 0; i < TT; ++i) {
                             av[i][0] = lp[i][o0]; av[i][1] = lp[i][o1]; av[i][2] = lp[i][o2]; av[i][3] = lp[i][o3];
                         }
 #pragma unroll
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
                         for (int h = 0; h < 4; ++h)
 #pragma unroll
-                            for (int i = 0; i < TI; ++i)
+                            for (int i = 0; i < TT; ++i)
 #pragma unroll
                                 for (int j = 0; j < NT; ++j)
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j][h], av[i][h], acc[i][j], 0, 0, 0);
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                             const float b0 = lbias[n0], b1 = lbias[n0 + 1], b2 = lbias[n0 + 2], b3 = lbias[n0 + 3];
                             const bool full4 = n0 + 3 < g.N;
 #pragma unroll
-                            for (int i = 0; i < TI; ++i) {
+                            for (int i = 0; i < TT; ++i) {
                                 // branch-free: a masked pixel writes its four values to the spare word (stride 0)
                                 const bool ok = outoff[i] >= 0;
                                 float* base = ok ? lout + outoff[i] + n0 * OHW : dummy;
@@ -400,6 +404,10 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                         }
                     }
                 }
+            };
+            for (int t0 = wid - c.w0; t0 < ntile; t0 += c.nw * TI) {
+                if (TI > 1 && t0 + c.nw >= ntile) pass(std::integral_constant<int, 1>{}, t0);
+                else pass(std::integral_constant<int, TI>{}, t0);
             }
         }
         __syncthreads();
