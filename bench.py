@@ -24,7 +24,7 @@ M_BYTES_PER_SAMPLE = 178e3
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/r01_pmc_*.csv, corrected
 # as DESIGN.md states), measured at batch 4096 per launch (None for any other batch)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 32270816  # (2*7287.9 + 16938.7) KiB, profiles/r01_pmc_summary.csv
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 32271264  # (2*7288.1 + 16938.7) KiB, profiles/r01_pmc_summary.csv
 
 
 def cpu_baseline(seconds=15.0, B=4096):
