@@ -169,6 +169,17 @@ int vae_elbo_backward(const float* x_rec, const float* target, const float* mu, 
                       const float* gscale, float* dx_rec, float* dmu, float* dlogvar, int B,
                       int n_per_sample, int64_t t_sb, int64_t t_se, int latent, int bce,
                       vae_stream_t stream);
+/* vae_elbo_forward for callers that cannot allocate (code under hipGraph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): NO counterpart in the reference.  Same kernels, same result bit for bit, but the
+ * partial-sum scratch is a static 8 KiB device array inside the library (2*VAE_ELBO_BLOCKS floats per GPU, held
+ * until the process ends) instead of the `partials` argument; the call allocates and frees nothing.  Inputs of more
+ * than VAE_ELBO_NOALLOC_MAX_ELEMS reconstruction (B*n_per_sample) or latent (B*latent) elements are rejected with
+ * VAE_EINVAL.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams) race;
+ * calls on one stream are ordered and need no clearing in between (every word read is rewritten by the same call). */
+#define VAE_ELBO_NOALLOC_MAX_ELEMS ((int64_t)1 << 31)
+int vae_elbo_forward_noalloc(const float* x_rec, const float* target, const float* mu, const float* logvar,
+                             float* out, int B, int n_per_sample, int64_t t_sb, int64_t t_se, int latent, int bce,
+                             vae_stream_t stream);
 
 /* Fused flat Adam (torch.optim.Adam defaults semantics; draft_pipe.py:132, notebook :249).
  * tick: device int32[4] block {step count t, scratch (workgroups done: keep 0), float 1-b1^t, float 1-b2^t}, zeroed

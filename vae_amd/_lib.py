@@ -61,6 +61,7 @@ def lib():
     L.vae_conv_wgrad_partial_floats.restype = i64
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_elbo_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
+    L.vae_elbo_forward_noalloc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]
     L.vae_randn.argtypes = [vp, i64, vp, vp]
     L.vae_window_gather.argtypes = [vp, i32, i64, i32, vp, i32, vp, vp]
@@ -69,7 +70,7 @@ def lib():
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
     for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
-                 "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
+                 "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy"):
         getattr(L, name).restype = i32
     _lib = L
@@ -80,7 +81,7 @@ def lib():
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
-           "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
+           "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 
 

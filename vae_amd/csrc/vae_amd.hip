@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "chan.h"
 #include "common.h"
 #include "conv.h"
@@ -25,6 +27,8 @@ void vae_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vae_last_error(void) { return g_err; }
 
+static int scratch_for_current_device(float** out);
+
 extern "C" int vae_check_device(void) {
     int dev = 0;
     VAE_HIP(hipGetDevice(&dev));
@@ -32,7 +36,9 @@ extern "C" int vae_check_device(void) {
     VAE_HIP(hipGetDeviceProperties(&prop, dev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         VAE_FAIL(VAE_ENODEV, "device %d is %s, libvae_amd is built for gfx950 only", dev, prop.gcnArchName);
-    return VAE_OK;
+    // the library's per-device set-up: resolve the device address of the static scratch (vae_elbo_forward_noalloc)
+    float* p = nullptr;
+    return scratch_for_current_device(&p);
 }
 
 // ---- reference resolution ------------------------------------------------------------------
@@ -1371,6 +1377,48 @@ extern "C" int vae_elbo_forward(const float* x_rec, const float* target, const f
     return elbo_fwd_impl((hipStream_t)stream, x_rec, target, mu, logvar, out, partials, B, n_per_sample, t_sb, t_se,
                          latent, bce, 0);
 }
+// ---- criterion without a workspace argument and without allocation ---------------------------------
+// The partial-sum scratch of vae_elbo_forward lives in a file-scope device array instead of a caller buffer.  The
+// array's name is only a host-side stand-in: its device address is looked up once per device with
+// hipGetSymbolAddress and that pointer is what the kernels get.
+#define VAE_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[2 * VAE_ELBO_BLOCKS];  // 8 KiB per GPU, held until the process ends
+static float* g_scratch_ptr[VAE_MAX_DEVICES];  // device address of `scratch` on each device (nullptr: not looked up yet)
+static std::mutex g_scratch_mu;
+
+// Device pointer of `scratch` on the CURRENT device (looked up on the first call per device).
+static int scratch_for_current_device(float** out) {
+    int dev = 0;
+    VAE_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= VAE_MAX_DEVICES) VAE_FAIL(VAE_EINVAL, "device index %d beyond %d", dev, VAE_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* p = nullptr;
+        VAE_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (p == nullptr) VAE_FAIL(VAE_EHIP, "hipGetSymbolAddress(scratch) returned a null pointer on device %d", dev);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return VAE_OK;
+}
+
+extern "C" int vae_elbo_forward_noalloc(const float* x_rec, const float* target, const float* mu, const float* logvar,
+                                        float* out, int B, int n_per_sample, int64_t t_sb, int64_t t_se, int latent,
+                                        int bce, vae_stream_t stream) {
+    if (!x_rec || !target || !mu || !logvar || !out) VAE_FAIL(VAE_EINVAL, "elbo(noalloc): null pointer");
+    if (B < 1 || n_per_sample < 1 || latent < 1 || t_sb < 0 || t_se < 0) VAE_FAIL(VAE_EINVAL, "elbo(noalloc): bad shape");
+    if ((int64_t)B * n_per_sample > VAE_ELBO_NOALLOC_MAX_ELEMS || (int64_t)B * latent > VAE_ELBO_NOALLOC_MAX_ELEMS)
+        VAE_FAIL(VAE_EINVAL, "elbo(noalloc): %lld x %d reconstruction / %d latent elements exceed the maximum of %lld",
+                 (long long)B, n_per_sample, latent, (long long)VAE_ELBO_NOALLOC_MAX_ELEMS);
+    float* partials = nullptr;
+    const int rc = scratch_for_current_device(&partials);
+    if (rc) return rc;
+    // every element of the scratch that elbo_finalize_k reads is written by elbo_fwd_k of the same call (all
+    // VAE_ELBO_BLOCKS workgroups store their pair), so nothing has to be cleared between calls
+    return elbo_fwd_impl((hipStream_t)stream, x_rec, target, mu, logvar, out, partials, B, n_per_sample, t_sb, t_se,
+                         latent, bce, 0);
+}
+
 extern "C" int vae_elbo_backward(const float* x_rec, const float* target, const float* mu, const float* logvar,
                                  const float* gscale, float* dx_rec, float* dmu, float* dlogvar, int B,
                                  int n_per_sample, int64_t t_sb, int64_t t_se, int latent, int bce,
