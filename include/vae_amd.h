@@ -159,6 +159,17 @@ int64_t vae_conv_scratch_floats(const vae_op* op, int B);
  * end of vae_run_backward. */
 int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B);
 
+/* Whole-model path of the 1-D families (TCVAE: Encoders.py:76-107 + Decoders.py:57-78 + vae.py:20-23;
+ * multiscale_vae.py:48-220).  When the op array is a complete 1-D VAE program -- nenc x {N x [CONV 1xk stride 2, BN],
+ * LINEAR mu, LINEAR logvar}, REPARAM, LINEAR, N x [CONVT 1x2 stride 2, (BN)], SLICE0, [ELBO] -- vae_run_forward /
+ * vae_run_backward execute it as one launch per BatchNorm-delimited phase (2N forward, 2N backward, one gradient
+ * reduction) instead of several launches per layer; results are the same ops' results.  Returns the floats of WORK
+ * scratch that path needs at batch B for a flat parameter buffer of nflat floats, or 0 when the program does not
+ * match (host-only query).  The host stores the scratch reference in ops[0].r[11]; with r[11] = -1, under
+ * vae_set_collective (world > 1) or with VAE_AMD_SEQ1D=0 in the environment the program runs op by op.  A fused
+ * program's backward runs whole: vae_run_backward_range accepts only [0, n_ops) for it. */
+int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat);
+
 /* Standalone criterion (autograd path).  Replaces train.py:39-48 / notebook :141-151.
  * out: 3 floats (loss, recon, kld).  partials: >= 2*VAE_ELBO_BLOCKS floats of scratch.
  * Target element (b, j) is at target[b*t_sb + j*t_se]. */
@@ -186,6 +197,12 @@ int vae_elbo_forward_noalloc(const float* x_rec, const float* target, const floa
  * by the caller before the first step; the kernel works with t+1 and stores it (graph-replay safe). */
 int vae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t* tick, vae_stream_t stream);
+/* Same step with the hyper-parameters read from DEVICE memory at run time: hyper = float[4] {lr, beta1, beta2,
+ * eps}.  A captured graph of the train step then follows `optimizer.param_groups[0]['lr']` (LR schedulers,
+ * manual decay between epochs: the reference's drivers set lr once, draft_pipe.py:132, but torch.optim.Adam honours
+ * later changes) after a 16-byte refresh of `hyper`, without a re-capture. */
+int vae_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                        int32_t* tick, vae_stream_t stream);
 
 /* eps ~ N(0,1): Philox4x32-10 + Box-Muller; rng = device uint64[3] {seed, offset, 0 (scratch: keep 0)}; offset is
  * advanced on the device (replaces torch.randn_like at vae.py:17). */

@@ -179,13 +179,29 @@ def elbo_mse(x_rec, target, mu, logvar):
     return recon + k, recon, k
 
 
+class _BceSum(torch.autograd.Function):
+    """F.binary_cross_entropy(p, t, reduction='sum') restated (notebook :143): the forward clamps each log at
+    -100; the backward is torch's own formula (p - t) / max((1 - p) * p, 1e-12), NOT the derivative of the clamped
+    logs (they differ where p saturates at 0 or 1).  tests/test_oracle_golden.py pins both against torch's op."""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        ctx.save_for_backward(p, t)
+        logp = torch.clamp(torch.log(p), min=-100.0)
+        log1mp = torch.clamp(torch.log(1 - p), min=-100.0)
+        return -torch.sum(t * logp + (1 - t) * log1mp)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        return g * (p - t) / torch.clamp((1 - p) * p, min=1e-12), None
+
+
 def elbo_bce(x_rec, target, mu, logvar):
     """Notebook criterion (:141-151).  binary_cross_entropy clamps each log at -100."""
     p = x_rec.reshape(-1, 784)
     t = target.reshape(-1, 784)
-    logp = torch.clamp(torch.log(p), min=-100.0)
-    log1mp = torch.clamp(torch.log(1 - p), min=-100.0)
-    recon = -torch.sum(t * logp + (1 - t) * log1mp)
+    recon = _BceSum.apply(p, t)
     k = kld(mu, logvar)
     return recon + k, recon, k
 

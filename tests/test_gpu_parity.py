@@ -310,7 +310,10 @@ def test_backward_in_gradient_buckets_equals_one_pass(family):
     else:
         model, x = vae_amd.multiscale_vae.vae(3, 60, 15), 50 + 10 * torch.randn(200, 3, 60)
     model = model.to(DEV).train()
-    st = FusedTrainStep(model, vae_amd.optim.Adam(model.parameters(), lr=1e-3), 200, DEV, use_graph=False)
+    # (allow_seq1d=False: the whole-model 1-D path runs its backward whole; the data-parallel step, which is what
+    # uses the buckets, keeps the per-layer program)
+    st = FusedTrainStep(model, vae_amd.optim.Adam(model.parameters(), lr=1e-3), 200, DEV, use_graph=False,
+                        allow_seq1d=False)
     st.inject_eps = True
     st.x.copy_(x.to(DEV))
     st.eps.copy_(torch.randn(st.eps.shape, generator=torch.Generator().manual_seed(4)).to(DEV))

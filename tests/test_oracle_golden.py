@@ -54,3 +54,29 @@ def test_lin_size_matches_reference_shapes():
         pass
     else:
         raise AssertionError("lin_size must raise when the window is too short")
+
+
+def _saturated_bce_inputs():
+    """x_rec with exact 0 / 1, denormals and near-1 values against targets 0 / 1 / 0.5: the log clamp at -100 and
+    the max((1-p)p, 1e-12) of torch's backward (the reference calls F.binary_cross_entropy, notebook :143)."""
+    ps = torch.tensor([0.0, 1.0, 1e-45, 1e-38, 1e-30, 1e-7, 0.5, 1 - 6e-8, 1 - 1e-3, 0.999999])
+    ts = torch.tensor([0.0, 1.0, 0.5])
+    p = ps.repeat_interleave(3).repeat(784 * 2 // 30 + 1)[:784 * 2].reshape(2, 784).contiguous()
+    t = ts.repeat(10).repeat(784 * 2 // 30 + 1)[:784 * 2].reshape(2, 784).contiguous()
+    return p, t
+
+
+def test_bce_restatement_matches_torch_op_at_saturation():
+    import torch.nn.functional as F
+    p, t = _saturated_bce_inputs()
+    mu, lv = torch.zeros(2, 15), torch.zeros(2, 15)
+    p1 = p.clone().requires_grad_(True)
+    want = F.binary_cross_entropy(p1, t, reduction="sum")
+    (gw,) = torch.autograd.grad(want, p1)
+    p2 = p.clone().requires_grad_(True)
+    loss, recon, k = O.elbo_bce(p2, t, mu, lv)
+    (gg,) = torch.autograd.grad(loss, p2)
+    assert torch.isfinite(recon) and float(k) == 0.0
+    close(recon, want, rtol=1e-6, atol=0)
+    torch.testing.assert_close(gg, gw, rtol=1e-6, atol=0)
+    assert float(gg.abs().max()) >= 1e11  # the saturated elements really are in the 1/1e-12 regime

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvae_amd.so")
+LIB_PATH = os.environ.get("VAE_AMD_LIB") or os.path.join(_HERE, "csrc", "libvae_amd.so")  # (override: instrumented builds)
 
 # enums (include/vae_amd.h)
 OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
@@ -59,10 +59,13 @@ def lib():
     L.vae_conv_scratch_floats.restype = i64
     L.vae_conv_wgrad_partial_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_wgrad_partial_floats.restype = i64
+    L.vae_seq_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32, i32, i64]
+    L.vae_seq_scratch_floats.restype = i64
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_elbo_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_elbo_forward_noalloc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
     L.vae_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]
+    L.vae_adam_step_hyper.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
     L.vae_randn.argtypes = [vp, i64, vp, vp]
     L.vae_window_gather.argtypes = [vp, i32, i64, i32, vp, i32, vp, vp]
     L.vae_graph_begin.argtypes = [ctypes.POINTER(vp)]
@@ -70,7 +73,7 @@ def lib():
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
     for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
-                 "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
+                 "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy"):
         getattr(L, name).restype = i32
     _lib = L
@@ -80,8 +83,8 @@ def lib():
 # int fn(void* user, float* buf, int64 floats_per_rank, void* stream)  (include/vae_amd.h: vae_allgather_fn)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
-EXPORTS = ("vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
-           "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
+EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
+           "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 
 

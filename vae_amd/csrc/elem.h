@@ -154,10 +154,16 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
 // tick block (device): {int32 step count t, int32 workgroups done, float 1-b1^t, float 1-b2^t}.  Every workgroup
 // reads t and works with t+1; the last one to finish (a device-scope counter) stores t+1, so a captured graph
 // replays with the right bias correction and the step counter needs no kernel of its own.
+// hyper (optional, device): {lr, beta1, beta2, eps} read at run time instead of the by-value arguments, so a captured
+// graph follows the optimiser's current learning rate (an LR scheduler between replays) without a re-capture.
 __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                   float beta1, float beta2, float eps, int32_t* tick) {
+                                                   float beta1, float beta2, float eps, int32_t* tick,
+                                                   const float* __restrict__ hyper) {
     __shared__ float sbc[2];
+    if (hyper != nullptr) {
+        lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3];
+    }
     if (threadIdx.x == 0) {
         const int t = tick[0] + 1;
         sbc[0] = (float)(1.0 - pow((double)beta1, (double)t));

@@ -17,6 +17,7 @@
 #include "igemm.h"
 #include "lin.h"
 #include "wide.h"
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void vae_set_error(const char* fmt, ...) {
@@ -1254,6 +1255,8 @@ static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullp
     return VAE_OK;
 }
 
+#include "seq1d_host.h"
+
 // ---- executor --------------------------------------------------------------------------------
 static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, const int64_t* sizes, int n_bases,
                     int B, vae_stream_t stream) {
@@ -1284,6 +1287,11 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
                                int n_bases, int B, int training, vae_stream_t stream) {
     Ctx c;
     int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
+    if (rc) return rc;
+    {   // a whole 1-D VAE program runs as one launch per BatchNorm-delimited phase (seq1d.h)
+        static thread_local SqProgram sq;
+        if (sq_use(ops, n_ops, B, &sq)) return sq_forward(c, ops, &sq, training);
+    }
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
         if (i + 1 < n_ops && linear_siblings(ops[i], ops[i + 1])) {
             rc = linear_forward(c, ops[i], &ops[i + 1]);
@@ -1330,6 +1338,14 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
     if (bases[2] == nullptr) VAE_FAIL(VAE_EINVAL, "backward needs the GRAD space (2) bound");
     if (op_begin < 0 || op_end > n_ops || op_begin > op_end)
         VAE_FAIL(VAE_EINVAL, "backward: op range [%d, %d) outside the program of %d ops", op_begin, op_end, n_ops);
+    {
+        static thread_local SqProgram sq;
+        if (sq_use(ops, n_ops, B, &sq)) {
+            if (op_begin != 0 || op_end != n_ops)
+                VAE_FAIL(VAE_EINVAL, "backward: a fused 1-D program (seq1d) runs whole, not in op ranges");
+            return sq_backward(c, ops, &sq);
+        }
+    }
     // weight gradients accumulate with atomics: start from zero (cleared by the ELBO op's kernel when the range ends
     // with one: it runs first and nothing before it touches the GRAD space)
     const bool zero_in_elbo = zero_grads && op_end > op_begin && ops[op_end - 1].kind == VAE_OP_ELBO;
@@ -1366,6 +1382,13 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
 extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                                 int n_bases, int B, vae_stream_t stream) {
     return vae_run_backward_range(ops, n_ops, bases, base_sizes, n_bases, B, stream, 0, n_ops, 1);
+}
+
+extern "C" int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat) {
+    if (ops == nullptr || n_ops < 6 || B < 1 || nflat < 1 || !sq_enabled()) return 0;
+    static thread_local SqProgram sq;
+    if (!sq_match(ops, n_ops, &sq) || !sq_plan(sq.d, B)) return 0;
+    return sq_scratch_floats(sq.d, nflat);
 }
 
 // ---- standalone criterion, optimiser, rng ---------------------------------------------------
@@ -1438,7 +1461,15 @@ extern "C" int vae_adam_step(float* p, const float* g, float* m, float* v, int64
     if (!p || !g || !m || !v || !tick || n < 1) VAE_FAIL(VAE_EINVAL, "adam: bad argument");
     // tick block: {int32 t, int32 workgroups done, float bc1, float bc2}; the kernel bumps t itself
     hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, tick);
+                       beta2, eps, tick, (const float*)nullptr);
+    VAE_LAUNCH_CHECK("adam_step_k");
+    return VAE_OK;
+}
+extern "C" int vae_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                   int32_t* tick, vae_stream_t stream) {
+    if (!p || !g || !m || !v || !tick || !hyper || n < 1) VAE_FAIL(VAE_EINVAL, "adam: bad argument");
+    hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, 0.f, 0.f,
+                       0.f, tick, hyper);
     VAE_LAUNCH_CHECK("adam_step_k");
     return VAE_OK;
 }

@@ -124,7 +124,8 @@ class HipModule(nn.Module):
             cache.clear()
             cache["sig"] = sig
         if key not in cache:
-            b = ProgramBuilder(B, self._param_off, self._state_off, want_grads=torch.is_grad_enabled())
+            b = ProgramBuilder(B, self._param_off, self._state_off, want_grads=torch.is_grad_enabled(),
+                               nflat=self._flat.numel())
             self.emit_program(b, training)
             cache[key] = b.build()
         return cache[key]
@@ -146,6 +147,12 @@ class HipModule(nn.Module):
             work = prog.new_workspace(x0.device)
             prog.forward(work, flat, sflat, ext, self.training)
             return {n: prog.view(work, *prog.outputs[n]) for n in names}
+        if not self.training and self._bn_holders():
+            # the backward kernels implement the train-mode BatchNorm gradient (batch-statistic terms included);
+            # eval-mode BatchNorm has the affine-only gradient, which is not built: refuse instead of returning
+            # silently wrong gradients (the reference only runs eval under torch.no_grad(), train.py:77-79)
+            raise L.VaeAmdError("vae_amd: gradients through an eval-mode BatchNorm are not supported; call the model "
+                                "under torch.no_grad() in eval mode (as train.py:test does) or switch to .train()")
         outs = _ProgramFn.apply(self, prog, len(inputs), *inputs, *self._param_list)
         return dict(zip(names, outs))
 

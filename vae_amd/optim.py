@@ -42,7 +42,13 @@ class Adam(torch.optim.Optimizer):
             st["tick"] = torch.zeros(4, dtype=torch.int32, device=flat_p.device)
         return st["m"], st["v"], st["tick"]
 
-    def launch(self, group, p, g, m, v, tick, stream=None):
+    def launch(self, group, p, g, m, v, tick, stream=None, hyper=None):
+        """hyper: device float[4] {lr, beta1, beta2, eps} read by the kernel at run time (captured graphs)."""
+        if hyper is not None:
+            L.check(L.lib().vae_adam_step_hyper(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper),
+                                                L.ptr(tick), stream if stream is not None else L.stream_ptr()),
+                    "vae_adam_step_hyper")
+            return
         b1, b2 = group["betas"]
         L.check(L.lib().vae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), group["lr"], b1, b2,
                                       group["eps"], L.ptr(tick), stream if stream is not None else L.stream_ptr()),

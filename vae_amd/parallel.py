@@ -92,7 +92,8 @@ class DataParallelTrainStep(FusedTrainStep):
     bucket follows.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
 
     def __init__(self, model, optimizer, B, device, bce=None, group=None):
-        super().__init__(model, optimizer, B, device, bce=bce, use_graph=False)
+        # (the whole-model 1-D path has no synchronised BatchNorm yet: data parallel keeps the per-layer program)
+        super().__init__(model, optimizer, B, device, bce=bce, use_graph=False, allow_seq1d=False)
         self.coll = Collective(group)
         if self.coll.world > L.MAX_WORLD:
             raise ValueError(f"world size {self.coll.world} > {L.MAX_WORLD}")
@@ -100,7 +101,10 @@ class DataParallelTrainStep(FusedTrainStep):
         for t in (self.flat, self.sflat):
             if t.numel():
                 self._broadcast(t)
-        self.rng[0] ^= (self.coll.rank + 1) * 0x9E3779B1  # a different eps stream per rank
+        # a different eps stream per rank, in a state of this stepper's own: the model's shared Philox state is left
+        # alone (XOR-ing it in place cancelled out when a second stepper was built on the same model)
+        self.rng = self.rng.clone()
+        self.rng[0] = (int(self.rng[0].item()) + (self.coll.rank + 1) * 0x9E3779B1) & ((1 << 62) - 1)
         self._hook_error = None
         self._hook = L.ALLGATHER_FN(self._allgather_hook)  # keep the thunk alive
         self.buckets = self.prog.grad_buckets()  # None: parameters interleave, one bucket
@@ -151,7 +155,7 @@ class DataParallelTrainStep(FusedTrainStep):
         for h in pending:
             if h is not None:
                 h.wait()
-        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream)
+        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream, hyper=self.hyper)
 
     def global_loss(self):
         """Sum of the shard losses of the last step (a host float; synchronises)."""

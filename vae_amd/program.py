@@ -35,9 +35,12 @@ class Buf:
 
 
 class ProgramBuilder:
-    def __init__(self, B, param_off, state_off, want_grads=True):
-        """param_off / state_off: dict id(tensor) -> float offset in the flat PARAM / STATE buffers."""
+    def __init__(self, B, param_off, state_off, want_grads=True, nflat=0, allow_seq1d=True):
+        """param_off / state_off: dict id(tensor) -> float offset in the flat PARAM / STATE buffers.
+        nflat: floats of the flat PARAM buffer (needed for the whole-model 1-D path, include/vae_amd.h
+        vae_seq_scratch_floats); allow_seq1d=False keeps a program on the per-layer path (data parallel)."""
         self.B = B
+        self.nflat, self.allow_seq1d = int(nflat), allow_seq1d
         self.ops = []
         self.work_size = 0
         self.param_off, self.state_off = param_off, state_off
@@ -200,14 +203,29 @@ class ProgramBuilder:
             bn.flags |= L.F_FUSED
             bn.r[1] = bn.r[3] = -1
 
+    def _seq1d(self):
+        """A complete 1-D VAE program (TCVAE / multiscale) runs as one launch per BatchNorm-delimited phase:
+        attach the scratch that path needs to ops[0].r[11].  Returns True when it applies."""
+        if not (self.allow_seq1d and self.nflat > 0 and len(self.ops) >= 6):
+            return False
+        arr = (L.VaeOp * len(self.ops))(*self.ops)
+        need = L.lib().vae_seq_scratch_floats(arr, len(self.ops), self.B, self.nflat)
+        if need <= 0:
+            return False
+        self.ops[0].r[11] = self.fixed(need)
+        return True
+
     def build(self):
-        if os.environ.get("VAE_AMD_UNFUSED", "0") != "1":
+        self.seq1d = self._seq1d()
+        if not self.seq1d and os.environ.get("VAE_AMD_UNFUSED", "0") != "1":
             self._fuse()
         scratch = self.fixed(self.scratch_need)  # shared: ops run back to back on one stream
         for op, slot in self._scratch_ops:
             op.r[slot] = scratch
         arr = (L.VaeOp * len(self.ops))(*self.ops)
-        return CompiledProgram(arr, len(self.ops), self.B, self.work_size, self.inputs, self.outputs)
+        prog = CompiledProgram(arr, len(self.ops), self.B, self.work_size, self.inputs, self.outputs)
+        prog.seq1d = self.seq1d
+        return prog
 
 
 class CompiledProgram:
@@ -268,7 +286,7 @@ class CompiledProgram:
         [(op_begin, op_end, grad_lo, grad_hi), ...] in backward order, or None when the parameter ranges of the two
         halves interleave in the flat buffer (then the whole gradient is one bucket)."""
         ks = [i for i in range(self.n_ops) if self.ops[i].kind == L.OP_REPARAM]
-        if len(ks) != 1:
+        if len(ks) != 1 or getattr(self, "seq1d", False):  # (a fused 1-D program's backward runs whole)
             return None
         k = ks[0]
 

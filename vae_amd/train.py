@@ -132,7 +132,7 @@ class FusedTrainStep:
     Inputs are copied into static device buffers (graph nodes hold fixed addresses); loss of
     the last step and the running sum live in device memory (`loss`, `total`)."""
 
-    def __init__(self, model, optimizer, B, device, bce=None, use_graph=True):
+    def __init__(self, model, optimizer, B, device, bce=None, use_graph=True, allow_seq1d=True):
         if not isinstance(model, HipVAE) or not isinstance(optimizer, Adam):
             raise TypeError("FusedTrainStep needs a vae_amd VAE model and vae_amd.optim.Adam")
         self.model, self.opt, self.B, self.device = model, optimizer, B, torch.device(device)
@@ -145,9 +145,10 @@ class FusedTrainStep:
         self.flat, self.sflat = flat, sflat
         self.m, self.v, self.tick = optimizer.flat_state(self.group, flat)
         self.grads = torch.zeros_like(flat)
-        for p, o in zip(plist, [model._param_off[id(p)] for p in plist]):
-            p.grad = self.grads[o:o + p.numel()].view(p.shape)  # p.grad stays meaningful for callers
-        b = ProgramBuilder(B, model._param_off, model._state_off, want_grads=True)
+        self._plist = plist
+        self.bind_grads()
+        b = ProgramBuilder(B, model._param_off, model._state_off, want_grads=True, nflat=flat.numel(),
+                           allow_seq1d=allow_seq1d)
         x = b.input("x", model._numel(model.in_shape))
         eps = b.input("eps", model.latent_total)
         mu, logvar = b.act(model.latent_total), b.act(model.latent_total)
@@ -166,10 +167,20 @@ class FusedTrainStep:
         out = self.prog.scalar_view(self.work, self.out_ref, 4)
         self.loss, self.total = out[0:1], out[3:4]
         self.rng = model._rng_state(self.device)
+        # Adam's {lr, beta1, beta2, eps} live in device memory and are re-read by the kernel at every replay, so a
+        # captured graph follows optimizer.param_groups[0] (LR schedulers) without a re-capture
+        self.hyper = torch.zeros(4, device=self.device)
+        self._hyper_host = None
         self.inject_eps = False  # tests set this and fill self.eps themselves
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0
+
+    def bind_grads(self):
+        """p.grad = view of this stepper's flat gradient buffer (stays meaningful for callers)."""
+        for p in self._plist:
+            o = self.model._param_off[id(p)]
+            p.grad = self.grads[o:o + p.numel()].view(p.shape)
 
     def _enqueue(self, stream):
         if not self.inject_eps:
@@ -177,7 +188,14 @@ class FusedTrainStep:
         ext = [self.x.view(self.B, -1), self.eps]
         self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
         self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
-        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream)
+        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream, hyper=self.hyper)
+
+    def _refresh_hyper(self):
+        g = self.group
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        if cur != self._hyper_host:
+            self.hyper.copy_(torch.tensor(cur, dtype=torch.float32))  # ordered on the current stream, before the step
+            self._hyper_host = cur
 
     def _capture(self):
         cs = ctypes.c_void_p()
@@ -197,6 +215,7 @@ class FusedTrainStep:
             if x.shape != self.x.shape:
                 raise ValueError(f"fused step was built for batches {tuple(self.x.shape)}, got {tuple(x.shape)}")
             self.x.copy_(x, non_blocking=True)
+        self._refresh_hyper()
         if self.use_graph:
             if self.graph is None or self._captured_inject != self.inject_eps:
                 if self.graph is not None:
@@ -228,12 +247,22 @@ def _fused_stepper(model, criterion_fn, optimizer, data):
     """Returns a FusedTrainStep when model/criterion/optimizer are all vae_amd's, else None."""
     if not (isinstance(model, HipVAE) and isinstance(optimizer, Adam) and criterion_fn in (criterion, criterion_bce)):
         return None
-    key = (data.shape[0], id(optimizer), criterion_fn.elbo_bce, str(data.device))
-    st = model.__dict__.get("_stepper")
-    if st is None or st[0] != key:
-        st = (key, FusedTrainStep(model, optimizer, data.shape[0], data.device, bce=criterion_fn.elbo_bce))
-        model.__dict__["_stepper"] = st
-    return st[1]
+    # one stepper per (batch size, optimizer, criterion, device): a loader without drop_last alternates between the
+    # full and the ragged last batch, and each keeps its program, workspace and hipGraph.  The flat parameter
+    # buffer's address is part of the key, so a repack (model.cpu().cuda(), load of unpacked weights) starts afresh.
+    flat, _ = model.pack(data.device)
+    key = (data.shape[0], id(optimizer), criterion_fn.elbo_bce, str(data.device), flat.data_ptr())
+    cache = model.__dict__.setdefault("_stepper", {})
+    st = cache.get(key)
+    if st is None:
+        for k in [k for k in cache if k[4] != key[4]]:  # steppers of a stale flat buffer train dead storage
+            del cache[k]
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        st = cache[key] = FusedTrainStep(model, optimizer, data.shape[0], data.device, bce=criterion_fn.elbo_bce)
+    else:  # p.grad views follow the stepper that ran last
+        st.bind_grads()
+    return st
 
 
 def _unpack(batch):
@@ -251,7 +280,7 @@ def train(model, train_loader, criterion, optimizer, device, epoch):
         if stepper is not None:
             loss = stepper.step(data)
             total_dev = loss.clone() if total_dev is None else total_dev.add_(loss)
-        else:  # generic autograd path (foreign criterion/optimizer, ragged last batch of another size...)
+        else:  # generic autograd path (foreign model, criterion or optimizer)
             optimizer.zero_grad()
             x_rec, mu, logvar = model(data)
             target = data[:, :, 0] if data.dim() == 3 else data
