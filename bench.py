@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py - train samples/s of the VAE hot path on MI355X (driver contract in the task).
 
-N=1 : BASELINE.json configs[1]: notebook MNIST Conv2d VAE, batch 4096, fp32, BCE ELBO, Adam.
-N>1 : configs[3]: same model, data-parallel, global batch 65536 split evenly, gradient
-      all-reduce SUM + synchronised BatchNorm statistics over RCCL.
+N=1 : BASELINE.json configs[1]: notebook MNIST Conv2d VAE, batch 4096, fp32, BCE ELBO, Adam ("weak": the per-GPU
+      batch is the fixed quantity of this point).  The same line carries `strong_scaling_ref`: one GPU at global
+      batch 65536, the N=1 point of the N>1 curve.
+N>1 : configs[3]: same model, data-parallel, global batch 65536 split evenly ("strong"), gradient all-reduce SUM +
+      synchronised BatchNorm statistics over RCCL.  `--batch B` fixes the per-GPU batch instead ("weak"),
+      `--global-batch G` the global one ("strong"), at any N.
 One step = eps draw + forward + ELBO + backward + Adam on a synthetic batch resident in HBM.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes
+through torch.distributed.run on 127.0.0.1, before this process touches a GPU) and relays rank 0's JSON line.
 """
 import argparse
+import csv
 import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -21,39 +29,140 @@ sys.path.insert(0, ROOT)
 # algorithmic figures per sample-step for the MNIST model
 M_FLOP_PER_SAMPLE = 1.89e6
 M_BYTES_PER_SAMPLE = 178e3
-HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (profiles/r01_pmc_*.csv, corrected
-# as DESIGN.md states), measured at batch 4096 per launch (None for any other batch)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 32271264  # (2*7288.1 + 16938.7) KiB, profiles/r01_pmc_summary.csv
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def cpu_baseline(seconds=15.0, B=4096):
-    """CPU oracle (oracle/vae_oracle.py, a port of the reference train loop) on the host cores:
-    zero_grad/forward/criterion/backward/Adam/loss.item() per step, same workload, bounded sample."""
-    from oracle import vae_oracle as O
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling: fixed as N grows)")
+    ap.add_argument("--global-batch", type=int, default=0, help="global batch, split evenly over the GPUs (strong scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-ref", action="store_true", help="skip the N=1 measurement at global batch 65536")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--model", default="mnist", choices=["mnist", "wide", "multiscale", "tcvae"],
+                    help="mnist = the contract workload (BASELINE configs[1]/[3]); multiscale / tcvae = configs[2] "
+                         "(dataGen-shaped windows, MSE ELBO); wide = configs[4]")
+    args = ap.parse_args()
+    if args.batch and args.global_batch:
+        ap.error("--batch (per GPU) and --global-batch exclude each other")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as children (never an exec: this process may not be
+    replaced once anything touched the GPU, and it has not touched it yet) and exit with their status.  With fewer
+    visible GPUs than ranks the ranks share the cards and rendezvous over gloo (a rehearsal of the N>1 code path)."""
+    import torch  # (device_count() does not initialise the GPU)
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ngpu < args.gpus and "VAE_BENCH_BACKEND" not in env:
+        env["VAE_BENCH_BACKEND"] = "gloo"
+        print(f"bench.py: {ngpu} GPU(s) visible for {args.gpus} ranks: ranks share the card(s), backend gloo (rehearsal)",
+              file=sys.stderr, flush=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode  # children inherit stdout: rank 0's JSON line goes straight out
+    if rc != 0:
+        print(f"bench.py: a rank failed (launcher exit status {rc})", file=sys.stderr, flush=True)
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
+def make_model(name, B, dev, gen):
+    import torch
     import vae_amd
+    if name in ("mnist", "wide"):
+        if name == "mnist":
+            model = vae_amd.mnist_vae.VariationalAutoencoder(15)
+            workload = "MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam"
+        else:  # BASELINE configs[4]; hidden width kept at 100 (SURVEY 8d asks to state the choice)
+            model = vae_amd.mnist_vae.VariationalAutoencoder(256, channels=(32, 64, 128), hidden=100)
+            workload = "widened MNIST Conv2d VAE (channels 32/64/128, latent 256, hidden 100), BCE ELBO, Adam"
+        x = torch.rand(B, 1, 28, 28, device=dev, generator=gen)
+    else:
+        if name == "multiscale":
+            model = vae_amd.multiscale_vae.vae(3, 60, 15)
+            workload = "multiscale_vae.vae(3, 60, 15) (12,255 params), MSE ELBO, Adam"
+        else:
+            model = vae_amd.VariationalAutoencoder(input_size=3, hidden_size=30, num_layers=3, latent_dims=15,
+                                                   v_encoder=vae_amd.Encoders.LongShort_TCVAE_Encoder,
+                                                   v_decoder=vae_amd.Decoders.LongShort_TCVAE_Decoder, L=60, slope=0.2,
+                                                   first_kernel=21)
+            workload = "TCVAE C=3 N=3 latent 15 L=60 first_kernel 21 (9,549 params), MSE ELBO, Adam"
+        x = 50 + 10 * torch.randn(B, 3, 60, device=dev, generator=gen)  # dataGen-shaped windows (SURVEY 8d cfg 2)
+    return model, x, workload
+
+
+# ------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_leg(name, B, seconds):
+    """The CPU oracle (oracle/vae_oracle.py, a port of the reference train loop: zero_grad / forward / criterion /
+    backward / Adam / loss.item() per step) on the host cores for about `seconds`."""
+    import torch
+    from oracle import vae_oracle as O
     torch.manual_seed(0)
-    m = vae_amd.mnist_vae.VariationalAutoencoder(15)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    model, x, _ = make_model(name, B, "cpu", torch.Generator().manual_seed(0))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    family, kw = {"mnist": ("mnist", {}), "wide": ("mnist", {}), "multiscale": ("multiscale", {}),
+                  "tcvae": ("tcvae", {"num_layers": 3})}[name]
+    lat = model.latent_total
     opt = O.Adam(sd, lr=1e-3)
-    g = torch.Generator().manual_seed(0)
-    x = torch.rand(B, 1, 28, 28, generator=g)
-    cores = torch.get_num_threads()
-    O.train_step("mnist", sd, opt, x, torch.randn(B, 15, generator=g))  # warm-up
+    g = torch.Generator().manual_seed(1)
+    O.train_step(family, sd, opt, x, torch.randn(B, lat, generator=g), **kw)  # warm-up
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        O.train_step("mnist", sd, opt, x, torch.randn(B, 15, generator=g))
+        O.train_step(family, sd, opt, x, torch.randn(B, lat, generator=g), **kw)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of batch {B} (MNIST VAE fwd+BCE ELBO+bwd+Adam) in {dt:.1f}s, torch CPU threads={cores}"}
+    return n, dt
 
 
-def dominant_kernel_roofline(stepper, iters):
-    """Roofline of the dominant kernel, igemm_gather_k<1, 2, false, 0> (the forward implicit-GEMM gather on MFMA
-    tiles of the conv / transposed-conv layers with <= 16 output channels that are not thin enough for the
-    vector-ALU variant: conv2, convT1, convT2 of this model; the largest line of profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch
-    stream (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
+def cpu_baseline(name, B):
+    """Bounded sample of the same workload on the host cores (kind "port": the oracle restates the reference's
+    loop), plus, for the MNIST model, the reference's own batch size 128 (BASELINE configs[0], notebook loaders)."""
+    import torch
+    cores = torch.get_num_threads()
+    n, dt = _cpu_leg(name, B, 12.0)
+    out = {"value": n * B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"{n} steps of batch {B} ({name} VAE fwd + ELBO + bwd + Adam) in {dt:.1f}s, torch CPU threads={cores}"}
+    if name == "mnist":
+        n2, dt2 = _cpu_leg(name, 128, 6.0)
+        out["reference_batch_128"] = {"value": n2 * 128 / dt2, "unit": "samples/s", "cores": cores,
+                                      "sample": f"{n2} steps of batch 128 (configs[0], the notebook's loader batch) in {dt2:.1f}s"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------- roofline
+def pmc_traffic(model_name, kernel, B):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.csv
+    for the MNIST model, profiles/rNN_<model>_pmc_summary.csv for the others; made by tools/pmc_summary.py from separate
+    --pmc passes at batch 4096, corrected as DESIGN.md states).  (None, reason) when there is none for this run."""
+    if B != 4096:
+        return None, f"PMC summaries were collected at batch 4096, this run uses {B}"
+    pat = "r[0-9][0-9]_pmc_summary.csv" if model_name == "mnist" else f"r[0-9][0-9]_{model_name}_pmc_summary.csv"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    if not files:
+        return None, f"no profiles/{pat}"
+    with open(files[-1], newline="") as f:
+        for row in csv.reader(f):
+            if row and row[0].replace("void ", "").startswith(kernel):
+                return int(float(row[-1])), "profiles/" + os.path.basename(files[-1])
+    return None, f"kernel {kernel} not in profiles/{os.path.basename(files[-1])}"
+
+
+def roofline_mnist(stepper, iters):
+    """Dominant kernel igemm_gather_k<1, 2, false, 0> (the forward implicit-GEMM gather on MFMA tiles of the conv /
+    transposed-conv layers with <= 16 output channels: conv2, convT1, convT2; the largest line of
+    profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch stream
+    (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
     achieved = algorithmic bytes per launch / average launch duration; algorithmic bytes of a launch =
     4 * B * (Cin*H*W + Cout*OH*OW) + 4 * weights + bias (input read once, output written once: DESIGN.md)."""
     from vae_amd import _lib as L
@@ -78,36 +187,107 @@ def dominant_kernel_roofline(stepper, iters):
     avg_us = sum(tot_ms) / iters / len(sel) * 1e3
     avg_bytes = sum(b for _, b in sel) / len(sel)
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
+    kernel = "igemm_gather_k<1, 2, false, 0>"
+    traffic, src = pmc_traffic("mnist", kernel, stepper.B)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if stepper.B == 4096 else None, "kernel": "igemm_gather_k<1, 2, false, 0>",
+            "traffic": traffic, "traffic_source": src, "kernel": kernel,
             "launches_per_step": len(sel), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": avg_bytes,
             "per_launch_us": [t / iters * 1e3 for t in tot_ms],
             "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--roofline-iters", type=int, default=20)
-    ap.add_argument("--model", default="mnist", choices=["mnist", "wide", "multiscale", "tcvae"],
-                    help="mnist = the contract workload (BASELINE configs[1]/[3]); multiscale / tcvae = configs[2] "
-                         "(dataGen-shaped windows, MSE ELBO) for the record in DESIGN.md")
-    args = ap.parse_args()
+def roofline_seq1d(stepper, iters, model_name):
+    """1-D models on the fused path (seq1d.h: one launch per BatchNorm-delimited phase): every launch of forward +
+    backward is timed with HIP events on the launch stream (vae_time_seq); the dominant kernel is the phase with the
+    largest average duration.  Algorithmic bytes of a phase: its activations in and out once, weights included
+    (seq1d_host.h: sq_mark)."""
+    prog = stepper.prog
+    ext = [stepper.x.view(stepper.B, -1), stepper.eps]
+    acc = None
+    for it in range(iters + 2):
+        rows = prog.time_seq(stepper.work, stepper.flat, stepper.grads, stepper.sflat, ext)
+        if it >= 2:
+            if acc is None:
+                acc = [[t, 0.0, b] for t, _, b in rows]
+            for a, (_, ms, _) in zip(acc, rows):
+                a[1] += ms
+    phases = [{"phase": t, "avg_us": ms / iters * 1e3, "algorithmic_bytes": b} for t, ms, b in acc]
+    top = max(phases, key=lambda p: p["avg_us"])
+    kname = {"fe": "sq_fe_k", "fh": "sq_fh_k", "fd": "sq_fd_k", "bd": "sq_bd_k", "bh": "sq_bh_k", "be": "sq_be_k"}[top["phase"][:2]]
+    achieved = top["algorithmic_bytes"] / (top["avg_us"] * 1e-6) / 1e9
+    traffic, src = pmc_traffic(model_name, kname, stepper.B)
+    tot_us = sum(p["avg_us"] for p in phases)
+    tot_b = sum(p["algorithmic_bytes"] for p in phases)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "kernel": f"{kname} (phase {top['phase']})",
+            "avg_launch_us": top["avg_us"], "algorithmic_bytes_per_launch": top["algorithmic_bytes"],
+            "launches_per_step": len(phases) + (2 if not stepper.inject_eps else 1),  # + randn + adam
+            "all_phases": phases, "all_phases_GBps": tot_b / (tot_us * 1e-6) / 1e9,
+            "timing": f"HIP events on the launch stream, {iters} eager forward+backward passes"}
 
+
+def roofline_wide(stepper, iters):
+    """Widened model: the convolutions run on fp32 MFMA tiles (wide.h) and are matrix-bound; the dominant forward
+    launch is the conv op with the largest duration.  flops = 2 * B * Cout*OH*OW * Cin*KH*KW per launch."""
+    from vae_amd import _lib as L
+    prog = stepper.prog
+    ext = [stepper.x.view(stepper.B, -1), stepper.eps]
+    tot = [0.0] * prog.n_ops
+    for it in range(iters + 2):
+        ms = prog.time_forward(stepper.work, stepper.flat, stepper.sflat, ext, True)
+        if it >= 2:
+            tot = [a + b for a, b in zip(tot, ms)]
+    convs = [i for i in range(prog.n_ops) if prog.ops[i].kind in (L.OP_CONV, L.OP_CONVT)]
+    i = max(convs, key=lambda k: tot[k])
+    op = prog.ops[i]
+    cin, H, W, cout, OH, OW, KH, KW = [op.d[j] for j in range(8)]
+    if op.kind == L.OP_CONV:
+        flops = 2.0 * stepper.B * cout * OH * OW * cin * KH * KW
+    else:  # transposed: every input pixel meets every tap
+        flops = 2.0 * stepper.B * cin * H * W * cout * KH * KW
+    us = tot[i] / iters * 1e3
+    achieved = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": "matrix-bound kernel: see profiles/*wide_sq_counters.csv",
+            "kernel": f"wide conv op {i} ({'conv' if op.kind == L.OP_CONV else 'convT'} {cin}->{cout}, {H}x{W} -> {OH}x{OW}, k{KH})",
+            "avg_launch_us": us, "algorithmic_flops_per_launch": flops,
+            "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
+
+
+# ------------------------------------------------------------------------------------------- main
+def timed_run(stepper, steps, warmup, barrier):
+    import torch
+    for _ in range(warmup):
+        stepper.step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        stepper.step()
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, e0.elapsed_time(e1) / steps
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # (does not return)
+
+    import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    local_rank %= max(torch.cuda.device_count(), 1)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ngpu = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("VAE_BENCH_BACKEND") or ("nccl" if ngpu >= world else "gloo")
+    local_rank %= ngpu
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = os.environ.get("VAE_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a box with one GPU
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -118,28 +298,22 @@ def main():
     import vae_amd
     from vae_amd.train import FusedTrainStep
 
-    B = args.batch or (4096 if world == 1 else 65536 // world)
+    if args.batch:
+        B, scaling = args.batch, "weak"
+    elif args.global_batch:
+        B, scaling = args.global_batch // world, "strong"
+    elif world == 1:
+        B, scaling = 4096, "weak"           # configs[1]
+    else:
+        B, scaling = 65536 // world, "strong"  # configs[3]
+    if B < 2:
+        raise SystemExit(f"per-GPU batch {B}: too small")
+    if args.global_batch and B * world != args.global_batch:
+        raise SystemExit(f"--global-batch {args.global_batch} does not split evenly over {world} GPUs")
+
     torch.manual_seed(0)
     g = torch.Generator(device=dev).manual_seed(rank)
-    if args.model in ("mnist", "wide"):
-        if args.model == "mnist":
-            model = vae_amd.mnist_vae.VariationalAutoencoder(15)
-            workload = "MNIST 28x28 Conv2d VAE (notebook model, 103,343 params), BCE ELBO, Adam"
-        else:  # BASELINE configs[4]; hidden width kept at 100 (SURVEY 8d asks to state the choice)
-            model = vae_amd.mnist_vae.VariationalAutoencoder(256, channels=(32, 64, 128), hidden=100)
-            workload = "widened MNIST Conv2d VAE (channels 32/64/128, latent 256, hidden 100), BCE ELBO, Adam"
-        x = torch.rand(B, 1, 28, 28, device=dev, generator=g)
-    else:
-        if args.model == "multiscale":
-            model = vae_amd.multiscale_vae.vae(3, 60, 15)
-            workload = "multiscale_vae.vae(3, 60, 15) (12,255 params), MSE ELBO, Adam"
-        elif args.model == "tcvae":
-            model = vae_amd.VariationalAutoencoder(input_size=3, hidden_size=30, num_layers=3, latent_dims=15,
-                                                   v_encoder=vae_amd.Encoders.LongShort_TCVAE_Encoder,
-                                                   v_decoder=vae_amd.Decoders.LongShort_TCVAE_Decoder, L=60, slope=0.2,
-                                                   first_kernel=21)
-            workload = "TCVAE C=3 N=3 latent 15 L=60 first_kernel 21 (9,549 params), MSE ELBO, Adam"
-        x = 50 + 10 * torch.randn(B, 3, 60, device=dev, generator=g)  # dataGen-shaped windows (SURVEY 8d cfg 2)
+    model, x, workload = make_model(args.model, B, dev, g)
     model = model.to(dev).train()
     opt = vae_amd.optim.Adam(model.parameters(), lr=1e-3)
     if world == 1:
@@ -154,17 +328,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        stepper.step()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        stepper.step()
-    e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, dev_ms = timed_run(stepper, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,32 +338,59 @@ def main():
         raise SystemExit(f"loss is {loss}: the step is not training")
 
     roof = None
-    if rank == 0 and args.model == "mnist":
-        roof = dominant_kernel_roofline(stepper, args.roofline_iters)  # (local launches only)
+    if rank == 0 and world == 1:
+        if args.model == "mnist":
+            roof = roofline_mnist(stepper, args.roofline_iters)
+        elif getattr(stepper.prog, "seq1d", False):
+            roof = roofline_seq1d(stepper, args.roofline_iters, args.model)
+        elif args.model == "wide":
+            roof = roofline_wide(stepper, args.roofline_iters)
+    elif rank == 0 and args.model == "mnist":
+        roof = roofline_mnist(stepper, args.roofline_iters)  # (local launches only)
     barrier()
+
+    strong_ref = None
+    if rank == 0 and world == 1 and scaling == "weak" and not args.batch and not args.no_strong_ref and args.model == "mnist":
+        # the N=1 point of the N>1 curve (configs[3]: global batch 65536), so scaling efficiency has a denominator
+        G = 65536
+        del stepper
+        torch.cuda.empty_cache()
+        m2, x2, _ = make_model(args.model, G, dev, g)
+        m2 = m2.to(dev).train()
+        st2 = FusedTrainStep(m2, vae_amd.optim.Adam(m2.parameters(), lr=1e-3), G, dev, use_graph=not args.no_graph)
+        st2.step(x2)
+        n2 = max(5, min(args.steps, 20))
+        dt2, dev2 = timed_run(st2, n2, 3, barrier)
+        strong_ref = {"n_gpus": 1, "global_batch": G, "value": G * n2 / dt2, "unit": "samples/s", "ms_per_step": dt2 / n2 * 1e3,
+                      "steps": n2, "note": "one GPU at the global batch of the N>1 (strong-scaling) runs"}
+        del st2, m2, x2
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        dev_ms = e0.elapsed_time(e1) / args.steps
+        if world == 1:
+            par = "single GPU, whole step as one hipGraph" if not args.no_graph else "single GPU, eager launches"
+        else:
+            coll = "RCCL" if backend == "nccl" else f"{backend} (rehearsal: ranks share {ngpu} GPU(s), collectives staged through the host)"
+            par = f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM ({coll})"
         line = {
             "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}, batch {B} per GPU, global batch {B * world}",
-                       "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": ("single GPU, whole step as one hipGraph" if world == 1 else
-                                       f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM (RCCL)")},
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": par, "backend": backend if world > 1 else None},
             "loss_per_sample": loss / B,
             "device_ms_per_step": dev_ms,
-            # whole-step figure against the materialised-activation traffic model of SURVEY 8d (178 KB/sample)
         }
         if args.model == "mnist":
+            # whole-step figure against the materialised-activation traffic model of SURVEY 8d (178 KB/sample)
             line["step_hbm_model_GBps"] = M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9
         if roof is not None:
             line["roofline"] = roof
+        if strong_ref is not None:
+            line["strong_scaling_ref"] = strong_ref
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.model, B)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

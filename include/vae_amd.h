@@ -133,6 +133,15 @@ int vae_run_backward_range(const vae_op* ops, int n_ops, float* const* bases, co
 int vae_time_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                      int n_bases, int B, int training, vae_stream_t stream, float* op_ms);
 
+/* Profiling twin of forward + backward for a fused 1-D program (the one vae_seq_scratch_floats accepted): a HIP event
+ * is recorded on `stream` before every launch of the phase kernels.  ms[k] = device time of launch k in milliseconds,
+ * bytes[k] = its algorithmic bytes (each input read once, each output written once, weights included), tags = 8
+ * chars per launch ("fe0".., "fh", "fd1".., "elbofin", "bd2".., "bh", "be2".., "reduce"); cap = room in the three
+ * arrays, *n_launches = launches written.  Needs the GRAD space bound.  Synchronises the stream; not capturable.
+ * VAE_EINVAL when the program does not run on that path.  bench.py's roofline for the 1-D models comes from it. */
+int vae_time_seq(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases, int B,
+                 vae_stream_t stream, float* ms, double* bytes, char* tags, int cap, int* n_launches);
+
 /* Data parallelism (one process per GPU).  The reference is single-device: with equal shards,
  * gradient all-reduce SUM (done by the host on the flat GRAD buffer) plus synchronised BatchNorm statistics
  * reproduce its result at the global batch.  For the latter the executor calls `fn` at every training-mode

@@ -49,6 +49,9 @@ def lib():
     L.vae_run_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp]
     L.vae_time_forward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp,
                                    ctypes.POINTER(ctypes.c_float)]
+    L.vae_time_seq.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
+                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, i32,
+                               ctypes.POINTER(i32)]
     L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
     L.vae_run_backward_range.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
                                          i32, i32, i32]
@@ -72,7 +75,7 @@ def lib():
     L.vae_graph_end.argtypes = [ctypes.POINTER(vp)]
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
-    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
+    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy"):
         getattr(L, name).restype = i32
@@ -83,7 +86,7 @@ def lib():
 # int fn(void* user, float* buf, int64 floats_per_rank, void* stream)  (include/vae_amd.h: vae_allgather_fn)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
-EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
+EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 

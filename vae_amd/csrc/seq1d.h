@@ -194,7 +194,7 @@ __device__ __forceinline__ void sq_tile_out(const SqIx& M, const SqIx& N, const 
 // flags: 1 accumulate (SQ_ACC), 2 LeakyReLU, 4 bias indexed by n
 SQ_FN void sq_gemm_f(int Mc, int Mn, int Mo1, int Mi1, int Mo2, int Mi2, int Nc, int Nn, int No1, int Ni1, int No2, int Ni2,
                      int Kcnt, const lds_i2* kt, const lds_f* A, const lds_f* Bm, lds_f* D, const lds_f* bias, int flags,
-                     float slope, int wrot) {
+                     float slope, int wrot, lds_f* ksc) {
     const SqIx M = sq_ix(Mc, Mn, Mo1, Mi1, Mo2, Mi2), N = sq_ix(Nc, Nn, No1, Ni1, No2, Ni2);
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -202,6 +202,45 @@ SQ_FN void sq_gemm_f(int Mc, int Mn, int Mo1, int Mi1, int Mo2, int Mi2, int Nc,
     const int mtiles = (M.cnt + 15) >> 4, ntiles = (N.cnt + 15) >> 4, ntot = mtiles * ntiles;
     const int kpad = (Kcnt + 15) & ~15;
     const lds_i2* ktl = kt + lk;
+    if (ksc != nullptr && 2 * ntot <= SQ_WAVES && kpad >= 64) {
+        // Few tiles, long K (a weight gradient: K = the chunk's pixels): the K range is split over ks waves per tile.
+        // Every wave leaves its partial tile in LDS, and the tile's first wave adds the slices in a fixed order
+        // (deterministic) and writes the result.  All waves of the workgroup call with the same arguments, so the
+        // barriers are uniform.
+        const int ks = SQ_WAVES / ntot;
+        const int t = wid / ks, slice = wid - t * ks;
+        const bool active = t < ntot;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        SqTile q = sq_tile(M, N, active ? t : 0, ntiles, A, Bm, li);
+        if (active) {
+            const int iters = kpad >> 4, per = (iters + ks - 1) / ks;
+            const int k_lo = slice * per * 16, k_hi = min(kpad, (slice + 1) * per * 16);
+            for (int k4 = k_lo; k4 < k_hi; k4 += 16) {
+                const i32x2 o0 = ktl[k4], o1 = ktl[k4 + 4], o2 = ktl[k4 + 8], o3 = ktl[k4 + 12];
+                float a0 = q.Ap[o0.x], a1 = q.Ap[o1.x], a2 = q.Ap[o2.x], a3 = q.Ap[o3.x];
+                float b0 = q.Bp[o0.y], b1 = q.Bp[o1.y], b2 = q.Bp[o2.y], b3 = q.Bp[o3.y];
+                const int kk = k4 + lk;
+                const bool v0 = kk < Kcnt, v1 = kk + 4 < Kcnt, v2 = kk + 8 < Kcnt, v3 = kk + 12 < Kcnt;
+                a0 = v0 ? a0 : 0.f; b0 = v0 ? b0 : 0.f;
+                a1 = v1 ? a1 : 0.f; b1 = v1 ? b1 : 0.f;
+                a2 = v2 ? a2 : 0.f; b2 = v2 ? b2 : 0.f;
+                a3 = v3 ? a3 : 0.f; b3 = v3 ? b3 : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+            }
+            ((lds_f4*)ksc)[wid * 64 + lane] = acc;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (active && slice == 0) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < ks; ++sl) tot += ((lds_f4*)ksc)[(t * ks + sl) * 64 + lane];
+            sq_tile_out(M, N, q, tot, D, bias, flags, slope, lk);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
     for (int t = w; t < ntot; t += 2 * SQ_WAVES) {
         const bool two = t + SQ_WAVES < ntot;  // (wave-uniform)
         const SqTile q0 = sq_tile(M, N, t, ntiles, A, Bm, li);
@@ -236,10 +275,10 @@ SQ_FN void sq_gemm_f(int Mc, int Mn, int Mo1, int Mi1, int Mo2, int Mi2, int Nc,
 }
 __device__ __forceinline__ void sq_gemm(const SqIx& M, const SqIx& N, int Kcnt, const int2* kt, const float* A,
                                         const float* Bm, float* D, const float* bias, int mode, int act, float slope,
-                                        int wrot = 0, int bias_n = 0) {
+                                        int wrot = 0, int bias_n = 0, float* ksc = nullptr) {
     sq_gemm_f(M.cnt, M.inner, M.o1, M.i1, M.o2, M.i2, N.cnt, N.inner, N.o1, N.i1, N.o2, N.i2, Kcnt, SQL2(kt), SQL(A), SQL(Bm),
               SQL(D), bias != nullptr ? SQL(bias) : (lds_f*)nullptr,
-              (mode == SQ_ACC ? 1 : 0) | (act ? 2 : 0) | (bias_n ? 4 : 0), slope, wrot);
+              (mode == SQ_ACC ? 1 : 0) | (act ? 2 : 0) | (bias_n ? 4 : 0), slope, wrot, ksc != nullptr ? SQL(ksc) : (lds_f*)nullptr);
 }
 
 // ---- LDS bump allocation (identical on host and device) -----------------------------------------------------
@@ -769,12 +808,10 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fe_k(SqDesc d, int i) {
         sq_dma_in(W[e], y.w, y.cout * K);
         sq_dma_in(Bi[e], y.b, y.cout);
     }
-    SQ_T(5);
     if (i > 0) {
         if (NENC == 2) sq_bn_prepare2(d.enc[0][i - 1], coef[0], d.enc[NENC - 1][i - 1], coef[NENC - 1], d.training);
         else sq_bn_prepare(d.enc[0][i - 1], coef[0], d.training);
     }
-    SQ_T(6);
     _Pragma("unroll") for (int e = 0; e < NENC; ++e) {
         const SqLayer& y = d.enc[e][i];
         sq_ktab(kt[e], sq_ix(y.cin * y.k, y.k, y.lin, 1, y.k, 1));
@@ -782,9 +819,6 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fe_k(SqDesc d, int i) {
     }
     sq_bar_dma();
     SQ_T(1);
-#ifdef SQ_TIMERS
-    if (threadIdx.x == 0 && blockIdx.x == 1) printf("fe setup: issue+dma %lld bnprep %lld ktab %lld ns\n", (tm_[5]-tm_[0])*10, (tm_[6]-tm_[5])*10, (tm_[1]-tm_[6])*10);
-#endif
     for (;;) {
         const int s0 = chunk * d.SB, sb = min(d.SB, d.B - s0);
         if (i > 0)
@@ -1052,17 +1086,17 @@ __host__ __device__ inline int sq_lds_bd(const SqDesc& d, int j, int SB) {
     l.take(y.cin * y.cout * 2); l.take(6 * y.cout); l.take(4 * y.cin);
     l.take(SQ_KT(2 * y.cout)); l.take(SQ_KT(SB * y.lin));
     l.take(SB * y.cin * y.lin); l.take(SB * y.cin * y.lin); l.take(SB * y.cout * y.lout); l.take(SB * y.cin * y.lin);
-    l.take(2 * y.cin); l.take(y.cin * y.cout * 2); l.take(y.cout);
+    l.take(2 * y.cin); l.take(SQ_WAVES * 256); l.take(y.cin * y.cout * 2); l.take(y.cout);
     return l.off;
 }
 // One transposed-conv layer, backward, on LDS tiles: dW[ci][(co,kk)] += sum IN*DP, db += sum DP,
 // GIN[s][ci][t] = sum_(co,kk) DP[s][co][2t+kk] W[ci][co][kk]
 __device__ __forceinline__ void sq_convT_bwd(const SqLayer& y, int sb, const int2* ktw, const int2* ktg, const float* IN,
-                                             const float* DP, const float* W, float* GIN, float* dW, float* db) {
+                                             const float* DP, const float* W, float* GIN, float* dW, float* db, float* ksc) {
     sq_gemm(sq_ix(sb * y.lin, y.lin, y.cout * y.lout, 2, y.cin * y.lin, 1), sq_ix(y.cin, 1, 2 * y.cout, 0, y.lin, 0), 2 * y.cout, ktg,
             DP, W, GIN, nullptr, SQ_STORE, 0, 0.f, 0);
     sq_gemm(sq_ix(y.cin, 1, y.lin, 0, 2 * y.cout, 0), sq_ix(2 * y.cout, 2, y.lout, 1, 2, 1), sb * y.lin, ktw, IN, DP, dW, nullptr,
-            SQ_ACC, 0, 0.f, SQ_WAVES / 2);
+            SQ_ACC, 0, 0.f, SQ_WAVES / 2, 0, ksc);
     sq_chan_sums(DP, sb, y.cout, y.lout, db);
 }
 __global__ __launch_bounds__(SQ_THREADS) void sq_bd_k(SqDesc d, int j) {
@@ -1086,6 +1120,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bd_k(SqDesc d, int j) {
     float* DP = smem + l.take(d.SB * y.cout * y.lout);
     float* GIN = smem + l.take(d.SB * y.cin * y.lin);
     float* wst = smem + l.take(2 * y.cin);
+    float* ksc = smem + l.take(SQ_WAVES * 256);
     float* dW = sq_blk(blk, smem, l, y.cin * y.cout * 2, y.w_off);
     float* db = sq_blk(blk, smem, l, y.cout, y.b_off);
     SqR2 ri;
@@ -1116,7 +1151,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bd_k(SqDesc d, int j) {
         sq_stage_bn_finish(ri, IN, XH, p.y + (int64_t)s0 * y.cin * y.lin, coefp, sb * y.cin * y.lin, y.cin, y.lin);
         sq_dpre_finish(rd, DP, gsrc, ysrc, coef, y.has_bn, sb * y.cout * y.lout, y.cout, y.lout, d.slope, last);
         sq_bar();
-        sq_convT_bwd(y, sb, ktw, ktg, IN, DP, W, GIN, dW, db);
+        sq_convT_bwd(y, sb, ktw, ktg, IN, DP, W, GIN, dW, db, ksc);
         sq_bar();
         sq_copy_out(p.g + (int64_t)s0 * y.cin * y.lin, GIN, sb * y.cin * y.lin);
         sq_tile_bsums(GIN, XH, sb, y.cin, y.lin, wst);
@@ -1261,7 +1296,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bh_k(SqDesc d) {
         }
         sq_bar_dma();
         SQ_T(2);
-        sq_convT_bwd(y0, sb, ktw, ktg, H0, DP, W0, DH, dW0, db0);
+        sq_convT_bwd(y0, sb, ktw, ktg, H0, DP, W0, DH, dW0, db0, nullptr);  // K = sb*lin is short here: no split
         sq_bar();
         SQ_T(3);
         // decoder Linear: dWl[n][k] += sum_s DH[s][n] Z[s][k];  dbl[n] += sum_s DH[s][n];  dz[s][k] = sum_n DH[s][n] Wl[n][k]
@@ -1327,7 +1362,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bh_k(SqDesc d) {
 // ---- backward: encoder layer i of every encoder -------------------------------------------------------------
 __host__ __device__ inline int sq_lds_be(const SqDesc& d, int i, int SB) {
     SqLds l = {0};
-    l.take(4 * SQ_MAXBLK);
+    l.take(4 * SQ_MAXBLK); l.take(SQ_WAVES * 256);
     if (i == 0) l.take(SB * d.C * d.L);
     for (int e = 0; e < d.nenc; ++e) {
         const SqLayer& y = d.enc[e][i];
@@ -1350,6 +1385,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_be_k(SqDesc d, int i) {
     SqBlocks blk;
     blk.n = 0;
     blk.tab = reinterpret_cast<int4*>(smem + l.take(4 * SQ_MAXBLK));
+    float* ksc = smem + l.take(SQ_WAVES * 256);
     SQ_T(0);
     float* X = i == 0 ? smem + l.take(d.SB * d.C * d.L) : nullptr;
     float *W[NENC], *coef[NENC], *coefp[NENC], *DP[NENC], *IN[NENC], *XH[NENC], *GIN[NENC];
@@ -1433,7 +1469,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_be_k(SqDesc d, int i) {
                         ktg[e], DP[e], W[e], GIN[e], nullptr, SQ_STORE, 0, 0.f, e * (SQ_WAVES / 2));
             // dW[co][(ci,kk)] += sum_(s,t) DP[s][co][t] IN[s][ci][2t+kk]
             sq_gemm(sq_ix(y.cout, 1, y.lout, 0, K, 0), sq_ix(K, y.k, y.lin, 1, y.k, 1), sb * y.lout, ktw[e], DP[e], IN[e], dW[e],
-                    nullptr, SQ_ACC, 0, 0.f, e * (SQ_WAVES / 2) + 2);
+                    nullptr, SQ_ACC, 0, 0.f, e * (SQ_WAVES / 2) + 2, 0, ksc);
             sq_chan_sums(DP[e], sb, y.cout, y.lout, db[e]);
         }
         sq_bar();

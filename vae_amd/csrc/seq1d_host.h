@@ -169,6 +169,12 @@ static bool sq_plan(SqDesc& d, int B) {
     if (sq_env_int("VAE_SEQ1D_VERBOSE", 0))
         fprintf(stderr, "[seq1d] B=%d SB=%d (fit %d) chunks=%d grid=%d lds(max)=%d floats\n", B, d.SB, fit, d.nchunks, d.grid,
                 sq_max_lds(d, d.SB));
+    if (sq_env_int("VAE_SEQ1D_VERBOSE", 0) > 1) {
+        fprintf(stderr, "[seq1d] lds floats at SB=%d: fh %d bh %d", fit + 1, sq_lds_fh(d, fit + 1), sq_lds_bh(d, fit + 1));
+        for (int i = 0; i < d.NE; ++i) fprintf(stderr, " fe%d %d be%d %d", i, sq_lds_fe(d, i, fit + 1), i, sq_lds_be(d, i, fit + 1));
+        for (int j = 1; j < d.ND; ++j) fprintf(stderr, " fd%d %d bd%d %d", j, sq_lds_fd(d, j, fit + 1), j, sq_lds_bd(d, j, fit + 1));
+        fprintf(stderr, " (budget %d)\n", SQ_LDS_BUDGET);
+    }
     return true;
 }
 static int64_t sq_scratch_floats(const SqDesc& d, int64_t nflat) {
@@ -307,21 +313,60 @@ static bool sq_use(const vae_op* ops, int n_ops, int B, SqProgram* p) {
     return sq_match(ops, n_ops, p) && sq_plan(p->d, B);
 }
 
-static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int training) {
+// Diagnostic timing of the phases (vae_time_seq): an event before every launch on the launch stream, with the
+// algorithmic bytes of the launch (each input read once, each output written once; weights included).
+#define SQ_MAX_MARKS 40
+struct SqTimer {
+    hipEvent_t ev[SQ_MAX_MARKS + 1];
+    double bytes[SQ_MAX_MARKS];
+    char tag[SQ_MAX_MARKS][8];
+    int n;
+    bool failed;
+};
+static void sq_mark(SqTimer* tm, hipStream_t s, const char* tag, double floats) {
+    if (tm == nullptr || tm->n >= SQ_MAX_MARKS) return;
+    if (hipEventRecord(tm->ev[tm->n], s) != hipSuccess) tm->failed = true;
+    tm->bytes[tm->n] = 4.0 * floats;
+    snprintf(tm->tag[tm->n], sizeof(tm->tag[0]), "%s", tag);
+    ++tm->n;
+}
+static double sq_layer_w(const SqLayer& y) { return (double)y.cin * y.cout * y.k + 3.0 * y.cout; }
+
+static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int training, SqTimer* tm = nullptr) {
     int rc = sq_bind(c, ops, p, training, false);
     if (rc) return rc;
     if ((rc = sq_grant_lds()) != VAE_OK) return rc;
     const SqDesc& d = p->d;
     if (training && (int64_t)c.B * d.dec[0].lout < 2) VAE_FAIL(VAE_EINVAL, "bn: training needs more than 1 value per channel");
+    const double Bd = (double)c.B;
+    char tag[8];
     for (int i = 0; i < d.NE; ++i) {
+        double fl = 0;
+        for (int e = 0; e < d.nenc; ++e) {
+            const SqLayer& y = d.enc[e][i];
+            fl += Bd * ((double)y.cin * y.lin + (double)y.cout * y.lout) + sq_layer_w(y);
+        }
+        snprintf(tag, sizeof(tag), "fe%d", i);
+        sq_mark(tm, c.s, tag, fl);
         if (d.nenc == 1) hipLaunchKernelGGL(sq_fe_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fe(d, i, d.SB) * sizeof(float), c.s, d, i);
         else hipLaunchKernelGGL(sq_fe_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fe(d, i, d.SB) * sizeof(float), c.s, d, i);
         VAE_LAUNCH_CHECK("sq_fe_k");
+    }
+    {
+        double fl = Bd * (4.0 * d.lat_total + d.dec[0].cin + (double)d.dec[0].cout * d.dec[0].lout) +
+                    (double)d.dec[0].cin * (d.lat_total + 1) + sq_layer_w(d.dec[0]);
+        for (int e = 0; e < d.nenc; ++e) fl += (Bd + 2.0 * d.lat) * d.head[e].K;
+        sq_mark(tm, c.s, "fh", fl);
     }
     if (d.nenc == 1) hipLaunchKernelGGL(sq_fh_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     else hipLaunchKernelGGL(sq_fh_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     VAE_LAUNCH_CHECK("sq_fh_k");
     for (int j = 1; j < d.ND; ++j) {
+        const SqLayer& y = d.dec[j];
+        double fl = Bd * ((double)y.cin * y.lin + (double)y.cout * y.lout) + sq_layer_w(y);
+        if (j == d.ND - 1) fl = Bd * ((double)y.cin * y.lin + (d.has_elbo ? 3.0 : 1.0) * y.cout) + sq_layer_w(y);  // only x[:, :, 0] leaves
+        snprintf(tag, sizeof(tag), "fd%d", j);
+        sq_mark(tm, c.s, tag, fl);
         hipLaunchKernelGGL(sq_fd_k, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fd(d, j, d.SB) * sizeof(float), c.s, d, j);
         VAE_LAUNCH_CHECK("sq_fd_k");
     }
@@ -330,13 +375,14 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
         bool ok = true;
         float* out = resolve(c, eo.r[4], 4, "seq1d.elbo.out", &ok);
         if (!ok) return VAE_EINVAL;
+        sq_mark(tm, c.s, "elbofin", 2.0 * d.grid + 4);
         hipLaunchKernelGGL(elbo_finalize_k, dim3(1), dim3(256), 0, c.s, d.epart, out, d.grid, eo.d[5]);
         VAE_LAUNCH_CHECK("elbo_finalize_k");
     }
     return rc;
 }
 
-static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p) {
+static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* tm = nullptr) {
     int rc = sq_bind(c, ops, p, 1, true);
     if (rc) return rc;
     if ((rc = sq_grant_lds()) != VAE_OK) return rc;
@@ -346,18 +392,38 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p) {
     if (!ok) return VAE_EINVAL;
     if (c.sizes[2] != d.nflat) VAE_FAIL(VAE_EINVAL, "seq1d: GRAD space (%lld floats) differs from PARAM (%lld)", (long long)c.sizes[2], (long long)d.nflat);
     // (with the criterion in the program, d(loss)/d(x_rec) was written by the last forward phase)
+    const double Bd = (double)c.B;
+    char tag[8];
     for (int j = d.ND - 1; j >= 1; --j) {
+        const SqLayer& y = d.dec[j];
+        const double gy = j == d.ND - 1 ? (double)y.cout : 2.0 * y.cout * y.lout;  // last layer: d(x_rec) only, no BatchNorm
+        snprintf(tag, sizeof(tag), "bd%d", j);
+        sq_mark(tm, c.s, tag, Bd * (gy + 2.0 * y.cin * y.lin) + 2.0 * sq_layer_w(y));
         hipLaunchKernelGGL(sq_bd_k, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bd(d, j, d.SB) * sizeof(float), c.s, d, j);
         VAE_LAUNCH_CHECK("sq_bd_k");
+    }
+    {
+        double fl = Bd * (2.0 * d.dec[0].cout * d.dec[0].lout + d.dec[0].cin + 4.0 * d.lat_total) +
+                    2.0 * ((double)d.dec[0].cin * (d.lat_total + 1) + sq_layer_w(d.dec[0]));
+        for (int e = 0; e < d.nenc; ++e) fl += (2.0 * Bd + 4.0 * d.lat) * d.head[e].K;
+        sq_mark(tm, c.s, "bh", fl);
     }
     if (d.nenc == 1) hipLaunchKernelGGL(sq_bh_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bh(d, d.SB) * sizeof(float), c.s, d);
     else hipLaunchKernelGGL(sq_bh_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bh(d, d.SB) * sizeof(float), c.s, d);
     VAE_LAUNCH_CHECK("sq_bh_k");
     for (int i = d.NE - 1; i >= 0; --i) {
+        double fl = 0;
+        for (int e = 0; e < d.nenc; ++e) {
+            const SqLayer& y = d.enc[e][i];
+            fl += Bd * (2.0 * y.cout * y.lout + (i > 0 ? 2.0 : 1.0) * y.cin * y.lin) + 2.0 * sq_layer_w(y);
+        }
+        snprintf(tag, sizeof(tag), "be%d", i);
+        sq_mark(tm, c.s, tag, fl);
         if (d.nenc == 1) hipLaunchKernelGGL(sq_be_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_be(d, i, d.SB) * sizeof(float), c.s, d, i);
         else hipLaunchKernelGGL(sq_be_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_be(d, i, d.SB) * sizeof(float), c.s, d, i);
         VAE_LAUNCH_CHECK("sq_be_k");
     }
+    sq_mark(tm, c.s, "reduce", (double)d.nflat * (d.grid + 1));
     hipLaunchKernelGGL(sq_reduce_k, dim3((unsigned)ceil_div64(d.nflat, 16)), dim3(256), 0, c.s, d.part, grad, d.nflat, d.grid);
     VAE_LAUNCH_CHECK("sq_reduce_k");
     return VAE_OK;

@@ -1330,6 +1330,43 @@ extern "C" int vae_time_forward(const vae_op* ops, int n_ops, float* const* base
     return rc;
 }
 
+// The fused 1-D path's forward + backward with a HIP event before every launch ON THE LAUNCH STREAM: ms[k], bytes[k]
+// (algorithmic bytes of launch k) and tags (8 chars per launch: fe0.., fh, fd1.., elbofin, bd.., bh, be.., reduce).
+// Synchronises the stream; not capturable.  VAE_EINVAL when the program is not a seq1d program.
+extern "C" int vae_time_seq(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases,
+                            int B, vae_stream_t stream, float* ms, double* bytes, char* tags, int cap, int* n_launches) {
+    if (ms == nullptr || bytes == nullptr || tags == nullptr || n_launches == nullptr || cap < 1)
+        VAE_FAIL(VAE_EINVAL, "time_seq: bad arguments");
+    Ctx c;
+    int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
+    if (rc) return rc;
+    if (bases[2] == nullptr) VAE_FAIL(VAE_EINVAL, "time_seq needs the GRAD space (2) bound");
+    static thread_local SqProgram sq;
+    if (!sq_use(ops, n_ops, B, &sq)) VAE_FAIL(VAE_EINVAL, "time_seq: not a fused 1-D (seq1d) program");
+    SqTimer* tm = new SqTimer;
+    tm->n = 0; tm->failed = false;
+    int made = 0;
+    for (; made <= SQ_MAX_MARKS; ++made)
+        if (hipEventCreate(&tm->ev[made]) != hipSuccess) break;
+    if (made <= SQ_MAX_MARKS) rc = VAE_EHIP, vae_set_error("time_seq: hipEventCreate failed");
+    if (rc == VAE_OK) rc = sq_forward(c, ops, &sq, 1, tm);
+    if (rc == VAE_OK) rc = sq_backward(c, ops, &sq, tm);
+    if (rc == VAE_OK && (tm->failed || hipEventRecord(tm->ev[tm->n], c.s) != hipSuccess ||
+                         hipEventSynchronize(tm->ev[tm->n]) != hipSuccess))
+        rc = VAE_EHIP, vae_set_error("time_seq: event record/synchronize failed");
+    if (rc == VAE_OK && tm->n > cap) rc = VAE_EINVAL, vae_set_error("time_seq: %d launches, room for %d", tm->n, cap);
+    for (int k = 0; k < tm->n && rc == VAE_OK; ++k) {
+        if (hipEventElapsedTime(&ms[k], tm->ev[k], tm->ev[k + 1]) != hipSuccess)
+            rc = VAE_EHIP, vae_set_error("hipEventElapsedTime failed");
+        bytes[k] = tm->bytes[k];
+        memcpy(tags + 8 * k, tm->tag[k], 8);
+    }
+    if (rc == VAE_OK) *n_launches = tm->n;
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(tm->ev[i]);
+    delete tm;
+    return rc;
+}
+
 extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                                       int n_bases, int B, vae_stream_t stream, int op_begin, int op_end, int zero_grads) {
     Ctx c;

@@ -267,6 +267,18 @@ class CompiledProgram:
                 "vae_time_forward")
         return list(ms)
 
+    def time_seq(self, work, params, grads, state, ext, stream=None):
+        """Forward + backward of a fused 1-D program with a HIP event before every launch on the launch stream;
+        returns [(tag, device ms, algorithmic bytes), ...] (vae_time_seq)."""
+        self._bind(work, params, grads, state, ext)
+        cap = 40
+        ms, nbytes = (ctypes.c_float * cap)(), (ctypes.c_double * cap)()
+        tags, n = ctypes.create_string_buffer(8 * cap), ctypes.c_int32(0)
+        L.check(L.lib().vae_time_seq(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                     stream if stream is not None else L.stream_ptr(), ms, nbytes, tags, cap,
+                                     ctypes.byref(n)), "vae_time_seq")
+        return [(tags.raw[8 * k:8 * k + 8].split(b"\0")[0].decode(), ms[k], nbytes[k]) for k in range(n.value)]
+
     def backward(self, work, params, grads, state, ext, stream=None):
         self._bind(work, params, grads, state, ext)
         L.check(L.lib().vae_run_backward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
