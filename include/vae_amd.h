@@ -84,7 +84,8 @@ enum {
  *                scale|sum_dy/n, shift|sum_dy_xhat/n, a, b, c, spare), 7 running_mean, 8 running_var
  *                (STATE), 9 partials / slab (WORK, shared scratch).  VAE_F_FUSED: 1 and 3 are -1.
  *             d: 0 C, 1 HW.   f[0]=eps f[1]=momentum
- *  LINEAR     r: 0 in, 1 out, 2 din(-1), 3 dout, 4 w [N][K], 5 b, 6 partials (WORK, 2*N*VAE_MAX_CHUNKS)
+ *  LINEAR     r: 0 in, 1 out, 2 din(-1), 3 dout, 4 w [N][K], 5 b, 6 partials (WORK, 2*N*VAE_MAX_CHUNKS),
+ *                10 the op's own weight-gradient partial region (WORK, vae_linear_wgrad_partial_floats; backward only)
  *             d: 0 K, 1 N, 2 ld_in, 3 ld_out, 4 ld_din, 5 ld_dout.   act NONE or LEAKY(0)
  *  REPARAM    r: 0 mu, 1 logvar, 2 eps, 3 z, 4 dz, 5 dmu(out), 6 dlogvar(out), 7 g_mu, 8 g_logvar
  *                (EXT_GRAD), 9 gscale (device float, KL_GRAD; -1 => 1.0)
@@ -167,6 +168,11 @@ int64_t vae_conv_scratch_floats(const vae_op* op, int B);
  * that need none).  The regions of different layers must not overlap: their reduction is deferred to one launch at the
  * end of vae_run_backward. */
 int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B);
+/* Floats of a LINEAR op's OWN weight-gradient partial region (r[10], WORK): one row of N*K + N floats per batch
+ * slice of the weight-gradient kernel.  The rows are added in a fixed order by the same launch that reduces the conv
+ * layers' partials, so Linear gradients are bit-identical from run to run (the reference's autograd on CPU is
+ * deterministic too: train.py:57-67).  Backward of a LINEAR op without the region fails with VAE_EINVAL. */
+int64_t vae_linear_wgrad_partial_floats(const vae_op* op, int B);
 
 /* Whole-model path of the 1-D families (TCVAE: Encoders.py:76-107 + Decoders.py:57-78 + vae.py:20-23;
  * multiscale_vae.py:48-220).  When the op array is a complete 1-D VAE program -- nenc x {N x [CONV 1xk stride 2, BN],

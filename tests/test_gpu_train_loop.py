@@ -84,3 +84,45 @@ def test_eval_mode_gradients_are_refused():
     with torch.no_grad():
         x_rec, mu, logvar = m(g["x"].to(DEV), eps=g["eps0"].to(DEV))
     assert torch.isfinite(x_rec).all()
+
+
+@pytest.mark.parametrize("stem", ["mnist_lat15", "multiscale_c3_l60"])
+def test_gradients_are_bit_identical_from_run_to_run(stem):
+    """No float atomics anywhere on the backward path (conv, Linear and the fused 1-D phases reduce per-workgroup rows
+    in a fixed order): two fused steps from the same state leave bit-identical GRAD buffers and parameters."""
+    import vae_amd
+    from vae_amd.train import FusedTrainStep
+    outs = []
+    for _ in range(2):
+        m, g = _model(stem)
+        opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
+        st = FusedTrainStep(m, opt, g["x"].shape[0], DEV, use_graph=False)
+        st.inject_eps = True
+        for step in range(2):
+            st.eps.copy_(g[f"eps{step}"])
+            st.step(g["x"].to(DEV))
+        torch.cuda.synchronize()
+        outs.append((st.grads.clone(), st.flat.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0] - outs[1][0]).abs().max())
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_wide_layer_gradients_are_bit_identical():
+    """The widened model (BASELINE configs[4]) takes the wide.h kernels: their split-reduction partials are summed in a
+    fixed order as well."""
+    import vae_amd
+    from vae_amd.train import FusedTrainStep
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        m = vae_amd.mnist_vae.VariationalAutoencoder(32, channels=(32, 64, 128), hidden=100).to(DEV).train()
+        opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
+        st = FusedTrainStep(m, opt, 256, DEV, use_graph=False)
+        st.inject_eps = True
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.rand(256, 1, 28, 28, device=DEV, generator=gen)
+        st.eps.copy_(torch.randn(256, 32, device=DEV, generator=gen))
+        st.step(x)
+        torch.cuda.synchronize()
+        outs.append(st.grads.clone())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

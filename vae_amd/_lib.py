@@ -62,6 +62,8 @@ def lib():
     L.vae_conv_scratch_floats.restype = i64
     L.vae_conv_wgrad_partial_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_wgrad_partial_floats.restype = i64
+    L.vae_linear_wgrad_partial_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
+    L.vae_linear_wgrad_partial_floats.restype = i64
     L.vae_seq_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32, i32, i64]
     L.vae_seq_scratch_floats.restype = i64
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
@@ -86,7 +88,7 @@ def lib():
 # int fn(void* user, float* buf, int64 floats_per_rank, void* stream)  (include/vae_amd.h: vae_allgather_fn)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
-EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
+EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
 

@@ -56,6 +56,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of
+// the wave (s_waitcnt vmcnt(0)): behind a chunk's copy-out that is 1-3 us of store latency per chunk which nothing
+// needs: a value loaded from global memory is waited for where it is used, and stores need no wait at all.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     if (act == VAE_ACT_LEAKY) return v > 0.f ? v : v * slope;
     if (act == VAE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));

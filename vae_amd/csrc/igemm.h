@@ -107,6 +107,16 @@ struct IgArgs {
     IgClass cls[4];
 };
 
+#ifdef IG_TIMERS  // diagnostic build only: phase stamps of workgroup 1 (wall clock, 10 ns ticks)
+#define IG_TDECL long long tm_[24]; int tn_ = 0
+#define IG_T() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 1 && tn_ < 24) tm_[tn_++] = wall_clock64(); } while (0)
+#define IG_TPRINT(name) do { if (threadIdx.x == 0 && blockIdx.x == 1) { printf("%s", name); for (int q_ = 1; q_ < tn_; ++q_) printf(" %lld", (tm_[q_] - tm_[q_-1]) * 10); printf(" ns\n"); } } while (0)
+#else
+#define IG_TDECL
+#define IG_T()
+#define IG_TPRINT(name)
+#endif
+
 #define IG_THREADS 512
 #define IG_WAVES (IG_THREADS / 64)
 #define IG_UNROLL 8
@@ -230,6 +240,8 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     float* cep = cin + 8 * g.Cin;                             // [8*N]   epilogue (producer BN) coefficients
     float* lbias = cep + 8 * g.N;                             // [Np]    bias (zero padded)
 
+    IG_TDECL;
+    IG_T();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int HpWp = g.Hp * g.Wp, CinHpWp = g.Cin * HpWp;
@@ -260,21 +272,20 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #undef MULTI
     }
 
-    for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
-        const int s0 = chunk * a.SB;
+    // Chunk loop, two LDS-only barriers per round:
+    //   [barrier] issue the loads of chunk c+1 | MFMA tiles of chunk c (lin -> lout)
+    //   [barrier] stage chunk c+1 into lin     | copy chunk c out of lout (+ statistics)
+    // The copy-out's global stores are never waited for by a barrier: they drain under the next chunk's MFMAs.
+    // The first round has no chunk to compute (chunk < 0) and only stages the workgroup's first one, so that the
+    // staging code exists once (a second inlined copy costs ~100 registers).
+    for (int chunk = -1, nx = blockIdx.x; chunk < a.nchunks; chunk = nx, nx += gridDim.x) {
+        const int s0 = max(chunk, 0) * a.SB;
         const int sb = min(a.SB, a.B - s0);
-        __syncthreads();  // previous chunk's copy-out is done with lout; tables/coefficients are ready
-        if (a.pre)
-            pre_store(a.in, cin, lin, (uint32_t)(sb * CHW), g.Cin, pr);
-        else
-            ig_stage(a.in, cin, lin, (int64_t)s0 * CHW, sb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
-                     g.d_CHW, g.d_HW, g.d_W);
-        __syncthreads();
-        {  // the next chunk's loads fly while this one is computed
-            const int nx = chunk + gridDim.x;
-            if (a.pre && nx < a.nchunks)
-                pre_load(a.in, (int64_t)nx * a.SB * CHW, (uint32_t)(min(a.SB, a.B - nx * a.SB) * CHW), pr);
-        }
+        lds_barrier();  // this chunk's image is staged (first round: tables ready); the previous copy-out is done with lout
+        IG_T();
+        if (chunk >= 0) {
+        if (a.pre && nx < a.nchunks)  // the next chunk's loads fly while this one is computed
+            pre_load(a.in, (int64_t)nx * a.SB * CHW, (uint32_t)(min(a.SB, a.B - nx * a.SB) * CHW), pr);
 
         // ---- output tiles: 16 pixels of one class x 16*NT channels, round-robin over the waves
         for (int cls = 0; cls < a.ncls; ++cls) {
@@ -410,7 +421,18 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 else pass(std::integral_constant<int, TI>{}, t0);
             }
         }
-        __syncthreads();
+        }  // chunk >= 0
+        lds_barrier();  // lout is complete, lin is free
+        IG_T();
+        if (nx < a.nchunks) {
+            const int cs0 = nx * a.SB, csb = min(a.SB, a.B - cs0);
+            if (a.pre)
+                pre_store(a.in, cin, lin, (uint32_t)(csb * CHW), g.Cin, pr);
+            else
+                ig_stage(a.in, cin, lin, (int64_t)cs0 * CHW, csb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
+                         g.d_CHW, g.d_HW, g.d_W);
+        }
+        if (chunk < 0) continue;
 
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
         const int64_t obase = (int64_t)s0 * g.N * OHW;
@@ -494,6 +516,13 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
         }
     }
+    IG_T();
+#ifdef IG_TIMERS
+    if (threadIdx.x == 0 && blockIdx.x == 1)
+        printf("gather<%d,%d,%d,%d> Cin %d N %d H %d OH %d SB %d chunks %d grid %d: setup | per chunk: top stage mfma | out ...", NT, TI, (int)GRAD, ND,
+               g.Cin, g.N, g.H, g.OH, a.SB, a.nchunks, (int)gridDim.x);
+#endif
+    IG_TPRINT("");
 }
 
 // ---- weight gradient --------------------------------------------------------------------------
@@ -535,6 +564,8 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
     float* cG = cS + 8 * a.Sc;                                // [8*Gc] ... of G
     float* bred = cG + 8 * a.Gc;                              // [IG_WAVES][64] bias partials
 
+    IG_TDECL;
+    IG_T();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int SHW = a.SH * a.SW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW;
@@ -586,6 +617,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
         const int sb = min(a.SB, a.B - s0);
         const int P = sb * SHW;
         __syncthreads();  // tables ready / previous chunk's MFMAs are done with the tiles
+        IG_T();
         if (a.pre) {
             pre_store(a.S, cS, lS, (uint32_t)(sb * SCHW), a.Sc, pS);
             pre_store(a.G, cG, lG, (uint32_t)(sb * GCHW), a.Gc, pG);
@@ -596,6 +628,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
                      a.dG_HW, a.dG_W);
         }
         __syncthreads();
+        IG_T();
         {  // the next chunk's loads fly while this one is computed
             const int nx = chunk + gridDim.x;
             if (a.pre && nx < a.nchunks) {
@@ -650,6 +683,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
         }
     }
     __syncthreads();
+    IG_T();
     // cross-wave reduction in LDS (rbuf overlays the dead S/G tiles; the host sizes them >= MT*NT*256);
     // the workgroup's partial goes to its own row of `part` in accumulator-tile order, bias sums behind it
     // (global atomics on the few cache lines of dw serialise in L2 and cost more than the whole MFMA loop)
@@ -692,6 +726,13 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
         for (int w = 0; w < IG_WAVES; ++w) t += bred[w * 64 + tid];
         row[MT * NT * 256 + tid] = t;
     }
+    IG_T();
+#ifdef IG_TIMERS
+    if (threadIdx.x == 0 && blockIdx.x == 1)
+        printf("wgrad<%d,%d> Sc %d Gc %d SH %d GH %d SB %d chunks %d grid %d: setup | per chunk: stage mfma(+bias) | ... reduce:", MT, NT, a.Sc, a.Gc,
+               a.SH, a.GH, a.SB, a.nchunks, (int)gridDim.x);
+#endif
+    IG_TPRINT("");
 }
 
 // Sum the workgroup partials of igemm_wgrad_k and add them into dw / dbias, for EVERY conv layer of a backward
@@ -704,7 +745,10 @@ struct WgFinLayer {
     float* dw;
     float* dbias;
     int nrows, NT, T, Sc, NK, C;
-    int first_block;  // the layer owns T*16 + 4 workgroups from here
+    int plain;        // 1: rows are [dw (Sc*NK floats, in dw's own order)][dbias (C floats)] (Linear layers); 0: MFMA tile order
+    int stride;       // floats per partial row
+    int ncols;        // columns to reduce (dw + bias sums)
+    int first_block;  // the layer owns ceil(ncols / 16) workgroups from here
 };
 struct WgFinMulti {
     WgFinLayer l[WG_FIN_MAX_LAYERS];
@@ -719,13 +763,13 @@ __global__ __launch_bounds__(256) void wgrad_finalize_k(WgFinMulti m) {
     const WgFinLayer& L = m.l[layer];
     const float* __restrict__ part = L.part;
     const int T = L.T, NT = L.NT, nrows = L.nrows;
-    const int stride = T * 256 + 64;
+    const int stride = L.stride;
     const int jj = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int j = ((int)blockIdx.x - L.first_block) * 16 + jj;
     float t[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) t[u] = 0.f;
-    int b = slice;
+    int b = j < L.ncols ? slice : nrows;  // (the last workgroup of a layer may reach past its columns)
     for (; b + 7 * 16 < nrows; b += 8 * 16)
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] += part[(int64_t)(b + u * 16) * stride + j];
@@ -736,7 +780,10 @@ __global__ __launch_bounds__(256) void wgrad_finalize_k(WgFinMulti m) {
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) sum += red[k][jj];
-    if (j < T * 256) {
+    if (L.plain) {
+        if (j < L.Sc * L.NK) L.dw[j] += sum;
+        else if (L.dbias != nullptr && j - L.Sc * L.NK < L.C) L.dbias[j - L.Sc * L.NK] += sum;
+    } else if (j < T * 256) {
         const int tile = j >> 8, r = (j >> 6) & 3, l = j & 63;
         const int mt = tile / NT, nt = tile - mt * NT;
         const int mrow = mt * 16 + (l >> 4) * 4 + r, n = nt * 16 + (l & 15);

@@ -10,7 +10,9 @@
 //                 forward (A' = x, W'(k,n) = W[n][k]) and input gradient
 //                 (A' = dY * act'(Y) taken on load, W'(k,n) = W[k][n]).
 //   lin_wgrad_k : dW[n][k] += sum_b dY'[b][n] * X[b][k],  db[n] += sum_b dY'[b][n]
-//                 (K of the MFMA = batch); one atomicAdd per element and workgroup.
+//                 (K of the MFMA = batch).  Every batch slice (workgroup column gx) writes its tile into its own
+//                 row of the layer's partial region; wgrad_finalize_k adds the rows in a fixed order, so the
+//                 gradient is bit-identical from run to run (no float atomics).
 #pragma once
 #include "common.h"
 #include "igemm.h"  // f32x4, FastDiv
@@ -191,6 +193,7 @@ struct LinWgArgs {
     const float* X;   // [B][K] rows ldx
     float* dW;        // [N][K]
     float* db;        // [N] or null
+    float* part;      // [gx][N*K + N] per-slice partials (the op's r[10] region)
     int lddy, ldy, ldx;
     int B, N, K;
     int act;
@@ -282,15 +285,16 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x1, acc1, 0, 0, 0);
         }
     }
-    if (a.db != nullptr && bz == 0 && tid < 32 && n0 + tid < a.N) atomicAdd(&a.db[n0 + tid], bsum);
+    float* const prow = a.part + (int64_t)bx * ((int64_t)a.N * a.K + a.N);
+    if (a.db != nullptr && bz == 0 && tid < 32 && n0 + tid < a.N) prow[(int64_t)a.N * a.K + n0 + tid] = bsum;
     // D: row (n) = lk*4 + r, col (k) = li
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + nt * 16 + lk * 4 + r;
         const int k = k0 + kt0 * 16 + li;
         if (n < a.N) {
-            if (k < a.K) atomicAdd(&a.dW[(int64_t)n * a.K + k], acc0[r]);
-            if (k + 16 < a.K) atomicAdd(&a.dW[(int64_t)n * a.K + k + 16], acc1[r]);
+            if (k < a.K) prow[(int64_t)n * a.K + k] = acc0[r];
+            if (k + 16 < a.K) prow[(int64_t)n * a.K + k + 16] = acc1[r];
         }
     }
 }

@@ -249,8 +249,7 @@ static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw,
         VAE_LAUNCH_CHECK("wide_wgrad_k");
         if (part != nullptr) {
             const int64_t n = (int64_t)A * wp.NK;
-            const int split = (int)(wp.chunks >= 128 ? 8 : wp.chunks >= 32 ? 4 : 1);
-            hipLaunchKernelGGL(wide_wgrad_reduce_k, dim3((unsigned)ceil_div64(n, 64), split), dim3(256), 0, c.s, part, dw, n,
+            hipLaunchKernelGGL(wide_wgrad_reduce_k, dim3((unsigned)ceil_div64(n, 64)), dim3(256), 0, c.s, part, dw, n,
                                (int)wp.chunks);
             VAE_LAUNCH_CHECK("wide_wgrad_reduce_k");
         }
@@ -548,13 +547,16 @@ static int wgrad_grid(const WgPlan& wp, int nchunks) {
 static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
     return (int64_t)wgrad_grid(wp, (B + wp.SB - 1) / wp.SB) * (wp.MT * wp.NT * 256 + 64);
 }
+static int flush_linear_wgrads(const Ctx& c);
 static int flush_wgrad_finalize(const Ctx& c) {
     WgFinMulti& m = c.wg_fin;
     if (m.n == 0) return VAE_OK;
+    int rc = flush_linear_wgrads(c);  // the Linear layers' partial rows must exist before they are reduced
+    if (rc) return rc;
     int blocks = 0;
     for (int i = 0; i < m.n; ++i) {
         m.l[i].first_block = blocks;
-        blocks += m.l[i].T * 16 + 4;
+        blocks += (m.l[i].ncols + 15) / 16;
     }
     hipLaunchKernelGGL(wgrad_finalize_k, dim3(blocks), dim3(256), 0, c.s, m);
     m.n = 0;
@@ -585,6 +587,7 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
     WgFinLayer& L = c.wg_fin.l[c.wg_fin.n++];
     L.part = wa.part; L.dw = dw; L.dbias = db; L.nrows = grid; L.NT = wp.NT; L.T = wp.MT * wp.NT;
     L.Sc = wa.Sc; L.NK = wa.Gc * wa.KH * wa.KW; L.C = wa.bias_from_S ? wa.Sc : wa.Gc;
+    L.plain = 0; L.stride = L.T * 256 + 64; L.ncols = L.stride;
     return VAE_OK;
 }
 
@@ -1031,6 +1034,26 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     return VAE_OK;
 }
 
+// Batch slices of a Linear weight gradient: ~512 workgroups per layer (all layers share one launch); every slice
+// owns a row of the layer's partial region.
+struct LinWgPlan { int gx, gy, gz, chunks_per_block; };
+static LinWgPlan lin_wgrad_plan(int B, int N, int K) {
+    LinWgPlan p;
+    const int tiles = ((N + 31) / 32) * ((K + 63) / 64);
+    const int nch = (B + LW_BB - 1) / LW_BB;
+    int gx = (512 + tiles - 1) / tiles;
+    if (gx > nch) gx = nch;
+    p.chunks_per_block = (nch + gx - 1) / gx;
+    p.gx = (nch + p.chunks_per_block - 1) / p.chunks_per_block;
+    p.gy = (N + 31) / 32; p.gz = (K + 63) / 64;
+    return p;
+}
+extern "C" int64_t vae_linear_wgrad_partial_floats(const vae_op* op, int B) {
+    if (op == nullptr || op->kind != VAE_OP_LINEAR || B < 1 || op->d[0] < 1 || op->d[1] < 1) return 0;
+    const int K = op->d[0], N = op->d[1];
+    return (int64_t)lin_wgrad_plan(B, N, K).gx * ((int64_t)N * K + N);
+}
+
 static int flush_linear_wgrads(const Ctx& c) {
     LinWgMulti& m = c.lin_wg;
     if (m.n == 0) return VAE_OK;
@@ -1116,19 +1139,31 @@ static int linear_backward(const Ctx& c, const vae_op& op, const vae_op* sib = n
     wa.dY = dy; wa.Y = y; wa.X = x; wa.dW = dw; wa.db = db;
     wa.lddy = lddy; wa.ldy = ldy; wa.ldx = ldx;
     wa.B = c.B; wa.N = N; wa.K = K; wa.act = op.act; wa.slope = op.f[0];
-    const int tiles = ((N + 31) / 32) * ((K + 63) / 64);
-    const int nch = (c.B + LW_BB - 1) / LW_BB;
-    int gx = (512 + tiles - 1) / tiles;  // ~512 workgroups per layer (all layers share one launch)
-    if (gx > nch) gx = nch;
-    wa.chunks_per_block = (nch + gx - 1) / gx;
-    gx = (nch + wa.chunks_per_block - 1) / wa.chunks_per_block;
-    wa.gx = gx; wa.gy = (N + 31) / 32; wa.gz = (K + 63) / 64;
-    // deferred: every Linear weight gradient of the pass goes into one launch (flush_linear_wgrads)
+    const LinWgPlan lp = lin_wgrad_plan(c.B, N, K);
+    wa.chunks_per_block = lp.chunks_per_block;
+    wa.gx = lp.gx; wa.gy = lp.gy; wa.gz = lp.gz;
+    if (op.r[10] < 0) VAE_FAIL(VAE_EINVAL, "linear: backward needs the op's weight-gradient partial region (r[10], vae_linear_wgrad_partial_floats)");
+    const int64_t prow = (int64_t)N * K + N;
+    wa.part = resolve(c, op.r[10], lp.gx * prow, "linear.wgrad_partials", &ok);
+    if (!ok) return VAE_EINVAL;
+    // deferred: every Linear weight gradient of the pass goes into one launch (flush_linear_wgrads), and the fixed-order
+    // sum of its per-slice rows into the conv layers' finalize launch (flush_wgrad_finalize)
     if (c.lin_wg.n == LIN_WG_MAX_LAYERS) {
         rc = flush_linear_wgrads(c);
         if (rc) return rc;
     }
     c.lin_wg.l[c.lin_wg.n++] = wa;
+    if (c.wg_fin.n == WG_FIN_MAX_LAYERS) {
+        rc = flush_wgrad_finalize(c);
+        if (rc) return rc;
+    }
+    {
+        WgFinLayer& F = c.wg_fin.l[c.wg_fin.n++];
+        memset(&F, 0, sizeof(F));
+        F.part = wa.part; F.dw = dw; F.dbias = db; F.nrows = lp.gx; F.NT = 1; F.T = 0;
+        F.Sc = N; F.NK = K; F.C = N;
+        F.plain = 1; F.stride = (int)prow; F.ncols = db != nullptr ? (int)prow : N * K;
+    }
     // 2) dX[B][K] (=|+=) (dY*act') W
     if (dx != nullptr && !skip_dgrad) {
         LinArgs b;
@@ -1412,8 +1447,8 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
             default: vae_set_error("op %d: unknown kind %d", i, op.kind); rc = VAE_EINVAL;
         }
     }
-    if (rc == VAE_OK) rc = flush_wgrad_finalize(c);
     if (rc == VAE_OK) rc = flush_linear_wgrads(c);
+    if (rc == VAE_OK) rc = flush_wgrad_finalize(c);
     return rc;
 }
 extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,

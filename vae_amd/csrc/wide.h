@@ -293,24 +293,25 @@ __global__ __launch_bounds__(WD_THREADS) void wide_wgrad_k(WideWgArgs a) {
             }
 }
 
-// dw[e] += sum over rows of part[row][e]: 64 elements x 4 row lanes per workgroup, grid.y further splits the rows
-// (a handful of float atomics per element at the end instead of one per workgroup of the gradient kernel).
+// dw[e] += sum over rows of part[row][e]: 64 elements x 4 row lanes per workgroup, four loads in flight per lane.
+// One workgroup owns an element and adds its rows in a fixed order: bit-identical from run to run (no float atomics).
 __global__ __launch_bounds__(256) void wide_wgrad_reduce_k(const float* __restrict__ part, float* __restrict__ dw,
                                                            int64_t n, int rows) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + tx;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < n) {
-        const int step = 4 * gridDim.y;
-        int r = blockIdx.y * 4 + ty;
-        for (; r + step < rows; r += 2 * step) {
+        int r = ty;
+        for (; r + 12 < rows; r += 16) {
             s0 += part[(int64_t)r * n + e];
-            s1 += part[(int64_t)(r + step) * n + e];
+            s1 += part[(int64_t)(r + 4) * n + e];
+            s2 += part[(int64_t)(r + 8) * n + e];
+            s3 += part[(int64_t)(r + 12) * n + e];
         }
-        if (r < rows) s0 += part[(int64_t)r * n + e];
+        for (; r < rows; r += 4) s0 += part[(int64_t)r * n + e];
     }
-    red[ty][tx] = s0 + s1;
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ty == 0 && e < n) atomicAdd(&dw[e], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+    if (ty == 0 && e < n) dw[e] += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }

@@ -140,6 +140,8 @@ class ProgramBuilder:
                          self.param(b) if b is not None else -1),
                       d=(K, N, x.ld, y.ld, x.ld, y.ld), f=(0.0,))
         self._need_scratch(op, 6, 2 * N * L.MAX_CHUNKS)
+        if self.want_grads:  # per-slice rows of the weight gradient (summed in a fixed order: deterministic)
+            op.r[10] = self.fixed(L.lib().vae_linear_wgrad_partial_floats(ctypes.byref(op), self.B))
         return y
 
     def reparam(self, mu, logvar, eps, latent, ext_grad=None, kl_grad=False, gscale=-1):
