@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--no-strong-ref", action="store_true", help="skip the N=1 measurement at global batch 65536")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="compute dtype of the matrix kernels: f32 (the headline) or bf16 operands with fp32 accumulate "
+                         "and fp32 storage (vae_set_compute_dtype; BASELINE configs[1] 'fp32 then bf16')")
     ap.add_argument("--model", default="mnist", choices=["mnist", "wide", "multiscale", "tcvae"],
                     help="mnist = the contract workload (BASELINE configs[1]/[3]); multiscale / tcvae = configs[2] "
                          "(dataGen-shaped windows, MSE ELBO); wide = configs[4]")
@@ -158,7 +161,7 @@ def pmc_traffic(model_name, kernel, B):
     return None, f"kernel {kernel} not in profiles/{os.path.basename(files[-1])}"
 
 
-def roofline_mnist(stepper, iters):
+def roofline_mnist(stepper, iters, bf16=False):
     """Dominant kernel igemm_gather_k<1, 2, false, 0> (the forward implicit-GEMM gather on MFMA tiles of the conv /
     transposed-conv layers with <= 16 output channels: conv2, convT1, convT2; the largest line of
     profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch stream
@@ -187,7 +190,7 @@ def roofline_mnist(stepper, iters):
     avg_us = sum(tot_ms) / iters / len(sel) * 1e3
     avg_bytes = sum(b for _, b in sel) / len(sel)
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
-    kernel = "igemm_gather_k<1, 2, false, 0>"
+    kernel = "igemm_gather_k<1, 2, false, 0, true>" if bf16 else "igemm_gather_k<1, 2, false, 0>"
     traffic, src = pmc_traffic("mnist", kernel, stepper.B)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel,
@@ -297,6 +300,7 @@ def main():
 
     import vae_amd
     from vae_amd.train import FusedTrainStep
+    vae_amd.set_compute_dtype(args.dtype)
 
     if args.batch:
         B, scaling = args.batch, "weak"
@@ -340,13 +344,13 @@ def main():
     roof = None
     if rank == 0 and world == 1:
         if args.model == "mnist":
-            roof = roofline_mnist(stepper, args.roofline_iters)
+            roof = roofline_mnist(stepper, args.roofline_iters, args.dtype == "bf16")
         elif getattr(stepper.prog, "seq1d", False):
             roof = roofline_seq1d(stepper, args.roofline_iters, args.model)
         elif args.model == "wide":
             roof = roofline_wide(stepper, args.roofline_iters)
     elif rank == 0 and args.model == "mnist":
-        roof = roofline_mnist(stepper, args.roofline_iters)  # (local launches only)
+        roof = roofline_mnist(stepper, args.roofline_iters, args.dtype == "bf16")  # (local launches only)
     barrier()
 
     strong_ref = None
@@ -376,12 +380,15 @@ def main():
         line = {
             "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{workload}, batch {B} per GPU, global batch {B * world}",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": par, "backend": backend if world > 1 else None},
             "loss_per_sample": loss / B,
             "device_ms_per_step": dev_ms,
         }
+        if args.dtype == "bf16":
+            line["dtype_note"] = "bf16 MFMA operands (rounded as they leave LDS), fp32 accumulate, fp32 storage, statistics, ELBO and Adam"
         if args.model == "mnist":
             # whole-step figure against the materialised-activation traffic model of SURVEY 8d (178 KB/sample)
             line["step_hbm_model_GBps"] = M_BYTES_PER_SAMPLE * B / (dev_ms * 1e-3) / 1e9

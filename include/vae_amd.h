@@ -143,6 +143,20 @@ int vae_time_forward(const vae_op* ops, int n_ops, float* const* bases, const in
 int vae_time_seq(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases, int B,
                  vae_stream_t stream, float* ms, double* bytes, char* tags, int cap, int* n_launches);
 
+/* Compute dtype of the matrix kernels (convolutions on the fused and wide paths, Linear layers), process-global.
+ * VAE_DTYPE_F32 (default): fp32 MFMA, results within the fp32 tolerance of the reference.  VAE_DTYPE_BF16: the MFMA
+ * operands are rounded to bf16 (round to nearest even) as they leave LDS, products accumulate in fp32; activations,
+ * parameters, gradients, BatchNorm statistics, sigmoid/ELBO and Adam stay fp32 in memory and arithmetic (the
+ * "fp32 then bf16" variant of BASELINE configs[1]; the reference itself is fp32 only, train.py:57-67).  Thin layers
+ * that run on the vector ALU (<= 8 output channels with a short reduction) compute in fp32 in both modes, and a
+ * fused 1-D program (vae_seq_scratch_floats) runs op by op under VAE_DTYPE_BF16.  Do not change it between the
+ * forward and the backward of one step, nor while a captured graph of the other dtype is replayed (a graph keeps the
+ * kernels it was captured with). */
+#define VAE_DTYPE_F32 0
+#define VAE_DTYPE_BF16 1
+int vae_set_compute_dtype(int dtype);
+int vae_get_compute_dtype(void);
+
 /* Data parallelism (one process per GPU).  The reference is single-device: with equal shards,
  * gradient all-reduce SUM (done by the host on the flat GRAD buffer) plus synchronised BatchNorm statistics
  * reproduce its result at the global batch.  For the latter the executor calls `fn` at every training-mode

@@ -64,6 +64,8 @@ def lib():
     L.vae_conv_wgrad_partial_floats.restype = i64
     L.vae_linear_wgrad_partial_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_linear_wgrad_partial_floats.restype = i64
+    L.vae_set_compute_dtype.argtypes = [i32]
+    L.vae_get_compute_dtype.argtypes = []
     L.vae_seq_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32, i32, i64]
     L.vae_seq_scratch_floats.restype = i64
     L.vae_elbo_forward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, i32, vp]
@@ -77,7 +79,7 @@ def lib():
     L.vae_graph_end.argtypes = [ctypes.POINTER(vp)]
     L.vae_graph_launch.argtypes = [vp, vp]
     L.vae_graph_destroy.argtypes = [vp]
-    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
+    for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy"):
         getattr(L, name).restype = i32
@@ -88,9 +90,26 @@ def lib():
 # int fn(void* user, float* buf, int64 floats_per_rank, void* stream)  (include/vae_amd.h: vae_allgather_fn)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
-EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
+EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy")
+
+
+_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+def set_compute_dtype(dtype):
+    """"f32" (default) or "bf16": the dtype of the matrix kernels' operands (include/vae_amd.h,
+    vae_set_compute_dtype: bf16 operands, fp32 accumulate, fp32 storage).  Process-global; programs and fused steppers
+    are cached per dtype, a stepper refuses to run under a dtype other than the one it was built for."""
+    key = str(dtype).replace("torch.", "")
+    if key not in _DTYPES:
+        raise ValueError(f"compute dtype {dtype!r}: expected 'f32' or 'bf16'")
+    check(lib().vae_set_compute_dtype(_DTYPES[key]), "vae_set_compute_dtype")
+
+
+def get_compute_dtype():
+    return "bf16" if lib().vae_get_compute_dtype() == 1 else "f32"
 
 
 def check(rc, what):

@@ -18,6 +18,19 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// bf16 compute mode (vae_set_compute_dtype): the MFMA operands are rounded to bf16 (round to nearest even,
+// v_cvt_pk_bf16_f32) when they leave LDS, products accumulate in fp32 (v_mfma_f32_16x16x16_bf16: 16 k-values per
+// instruction at 8x the fp32 matrix rate per k-value); everything stored in memory stays fp32.  Operand layout: lane
+// l supplies row/column l & 15 and the FOUR CONSECUTIVE k-values (l >> 4) * 4 + 0..3 of a 16-wide k block (the fp32
+// instruction takes one k-value per lane: (l >> 4) of a 4-wide block); the D layout is the same.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+__device__ __forceinline__ s16x4 bf16_pack4(float a, float b, float c, float d) {
+    bf16x4 h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+    return __builtin_bit_cast(s16x4, h);
+}
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 
 enum { TR_PLAIN = 0, TR_BN = 1, TR_GRAD_BN = 2, TR_GRAD_ACT = 3 };
 enum { EP_PLAIN = 0, EP_BNGRAD = 1 };
@@ -227,7 +240,7 @@ __device__ __forceinline__ void ig_load_coef(const float* g, float* l, int n) {
         for (int i = threadIdx.x; i < n; i += IG_THREADS) l[i] = g[i];
 }
 
-template <int NT, int TI, bool GRAD, int ND>
+template <int NT, int TI, bool GRAD, int ND, bool BF = false>
 __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_gather_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
@@ -363,6 +376,25 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
                         for (int i = 0; i < TT; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (BF) {  // one bf16 MFMA per 16 k-values: this lane's are k4 + lk*4 + 0..3
+                        const int* ktb = ktab + c.toff + lk * 4;
+                        const float* lwb = lw + c.woff + lk * 4 * g.Np + nc * 16 + li;
+                        for (int k4 = 0; k4 < c.KcPad; k4 += 16) {
+                            const int o0 = ktb[k4], o1 = ktb[k4 + 1], o2 = ktb[k4 + 2], o3 = ktb[k4 + 3];
+                            s16x4 av[TT], bw[NT];
+#pragma unroll
+                            for (int i = 0; i < TT; ++i) av[i] = bf16_pack4(lp[i][o0], lp[i][o1], lp[i][o2], lp[i][o3]);
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) {
+                                const float* wj = lwb + k4 * g.Np + (nc + j < n_ntile ? j * 16 : 0);
+                                bw[j] = bf16_pack4(wj[0], wj[g.Np], wj[2 * g.Np], wj[3 * g.Np]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                                for (int j = 0; j < NT; ++j) acc[i][j] = MFMA_BF16(bw[j], av[i], acc[i][j]);
+                        }
+                    } else {
                     const float* lwc = lw + c.woff + lk * g.Np + nc * 16 + li;
                     // KcPad is a multiple of 16: four independent k-steps per iteration
                     for (int k4 = 0; k4 < c.KcPad; k4 += 16) {
@@ -386,6 +418,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                                 for (int j = 0; j < NT; ++j)
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j][h], av[i][h], acc[i][j], 0, 0, 0);
                     }
+                    }  // fp32 operands
                     // A = weights, B = pixels: D row (channel) = lk*4 + r, col (pixel) = li, so every lane
                     // stores the four channels of its own pixel (no cross-lane traffic in the epilogue)
 #pragma unroll
@@ -554,7 +587,7 @@ struct WgArgs {
 // MT x NT accumulator tiles (16x16 each) per wave: compile-time so that every operand read of a step
 // is issued before its first MFMA and the loop has no branches.  Rows m >= Sc and columns
 // n >= Gc*KH*KW read a clamped (valid) row/column; their results are simply never written.
-template <int MT, int NT>
+template <int MT, int NT, bool BF = false>
 __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT * NT <= WG_SMALL_T ? 4 : 2, MT * NT <= WG_SMALL_T ? 4 : 2))) void igemm_wgrad_k(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lS = smem;                 // [sb][Sc][SHW]
@@ -652,6 +685,33 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
                 if (lane == c) bsum += t;
             }
         }
+        if constexpr (BF) {  // sixteen pixels per bf16 MFMA: this lane's are q16 + lk*4 + 0..3
+            for (int q16 = wid * 16; q16 < P; q16 += 16 * IG_WAVES) {
+                const int q0 = q16 + lk * 4;
+                int2 pp[4];
+                bool pv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pv[j] = q0 + j < P;
+                    pp[j] = ptab[pv[j] ? q0 + j : 0];
+                }
+                s16x4 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {  // pixels past the chunk: zero A column, finite B
+                    const float s0 = lS[pp[0].x + moff[mt]], s1 = lS[pp[1].x + moff[mt]];
+                    const float s2 = lS[pp[2].x + moff[mt]], s3 = lS[pp[3].x + moff[mt]];
+                    av[mt] = bf16_pack4(pv[0] ? s0 : 0.f, pv[1] ? s1 : 0.f, pv[2] ? s2 : 0.f, pv[3] ? s3 : 0.f);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bv[nt] = bf16_pack4(lG[pp[0].y + koffN[nt]], lG[pp[1].y + koffN[nt]], lG[pp[2].y + koffN[nt]],
+                                        lG[pp[3].y + koffN[nt]]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = MFMA_BF16(av[mt], bv[nt], acc[mt][nt]);
+            }
+        } else
         // pixels: four per MFMA step, two independent steps per iteration, steps round-robin over the waves
         for (int q4 = wid * 4; q4 < P; q4 += 8 * IG_WAVES) {
             const int qa = q4 + lk, qb = qa + 4 * IG_WAVES;

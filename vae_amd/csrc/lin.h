@@ -52,7 +52,7 @@ struct LinArgs {
 
 // VEC: rows are 16-byte aligned and K, N are multiples of 4 where it matters (host-checked), so the tile
 // is fetched with dwordx4 loads: a quarter of the load instructions, all of a pass in flight at once.
-template <bool VEC>
+template <bool VEC, bool BF = false>
 __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [32][Kp]
@@ -156,6 +156,16 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (BF) {  // (igemm.h: bf16 compute mode) this lane's k-values of a 16-wide block: lk*4 + 0..3
+            const float* apb = As + (mt * 16 + li) * a.Kp + lk * 4;
+            const float* wpb = Ws + lk * 4 * LIN_WS + nt * 16 + li;
+            for (int k4 = 0; k4 < a.KC; k4 += 16) {
+                const s16x4 av = bf16_pack4(apb[k4], apb[k4 + 1], apb[k4 + 2], apb[k4 + 3]);
+                const s16x4 bv = bf16_pack4(wpb[k4 * LIN_WS], wpb[(k4 + 1) * LIN_WS], wpb[(k4 + 2) * LIN_WS],
+                                            wpb[(k4 + 3) * LIN_WS]);
+                acc = MFMA_BF16(av, bv, acc);
+            }
+        } else
         for (int k4 = 0; k4 < a.KC; k4 += 16) {
             const float a0 = ap[k4], a1 = ap[k4 + 4], a2 = ap[k4 + 8], a3 = ap[k4 + 12];
             const float b0 = wp[k4 * LIN_WS], b1 = wp[(k4 + 4) * LIN_WS], b2 = wp[(k4 + 8) * LIN_WS],
@@ -212,6 +222,7 @@ struct LinWgMulti {
     int n;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+32)
     __shared__ float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
@@ -275,6 +286,19 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             for (int r = 0; r < LW_BB; ++r) t += Ys[r * LW_YS + tid];
             bsum += t;
         }
+        if constexpr (BF) {  // sixteen samples per bf16 MFMA: this lane's are b16 + lk*4 + 0..3
+            const float* ypb = Ys + lk * 4 * LW_YS + nt * 16 + li;
+            const float* xpb = Xs + lk * 4 * LW_XS + kt0 * 16 + li;
+#pragma unroll
+            for (int b16 = 0; b16 < LW_BB; b16 += 16) {
+                const s16x4 av = bf16_pack4(ypb[b16 * LW_YS], ypb[(b16 + 1) * LW_YS], ypb[(b16 + 2) * LW_YS], ypb[(b16 + 3) * LW_YS]);
+                const s16x4 x0 = bf16_pack4(xpb[b16 * LW_XS], xpb[(b16 + 1) * LW_XS], xpb[(b16 + 2) * LW_XS], xpb[(b16 + 3) * LW_XS]);
+                const s16x4 x1 = bf16_pack4(xpb[b16 * LW_XS + 16], xpb[(b16 + 1) * LW_XS + 16], xpb[(b16 + 2) * LW_XS + 16],
+                                            xpb[(b16 + 3) * LW_XS + 16]);
+                acc0 = MFMA_BF16(av, x0, acc0);
+                acc1 = MFMA_BF16(av, x1, acc1);
+            }
+        } else {
         const float* yp = Ys + lk * LW_YS + nt * 16 + li;
         const float* xp = Xs + lk * LW_XS + kt0 * 16 + li;
 #pragma unroll 4
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             const float x0 = xp[b4 * LW_XS], x1 = xp[b4 * LW_XS + 16];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x1, acc1, 0, 0, 0);
+        }
         }
     }
     float* const prow = a.part + (int64_t)bx * ((int64_t)a.N * a.K + a.N);

@@ -309,7 +309,8 @@ static int sq_grant_lds() {
 
 // true: the op array is a seq1d program (matched, scratch attached, single GPU)
 static bool sq_use(const vae_op* ops, int n_ops, int B, SqProgram* p) {
-    if (n_ops < 6 || ops[0].r[11] < 0 || g_world > 1 || !sq_enabled()) return false;
+    // (fp32 only: under the bf16 compute dtype the program runs op by op on the kernels that have bf16 instances)
+    if (n_ops < 6 || ops[0].r[11] < 0 || g_world > 1 || g_bf16 || !sq_enabled()) return false;
     return sq_match(ops, n_ops, p) && sq_plan(p->d, B);
 }
 

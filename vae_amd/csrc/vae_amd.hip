@@ -47,6 +47,7 @@ extern "C" int vae_check_device(void) {
 static vae_allgather_fn g_allgather = nullptr;
 static void* g_allgather_user = nullptr;
 static int g_rank = 0, g_world = 1;
+static int g_bf16 = 0;  // vae_set_compute_dtype: 1 = bf16 MFMA operands (fp32 accumulate, fp32 storage)
 
 struct Ctx {
     float* const* bases;
@@ -161,11 +162,15 @@ static int launch_conv_gather(const Ctx& c, const float* x, const float* w, cons
         const int kpad = (int)ceil_div64(K, 16) * 16;
         if (g.Cout <= 32) {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32);
-            hipLaunchKernelGGL((wide_gather_k<false, 1>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+            if (g_bf16) hipLaunchKernelGGL((wide_gather_k<false, 1, true>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
+            else hipLaunchKernelGGL((wide_gather_k<false, 1>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         } else {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64);
-            hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+            if (g_bf16) hipLaunchKernelGGL((wide_gather_k<false, 2, true>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
+            else hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         }
         VAE_LAUNCH_CHECK("wide_gather_k");
@@ -192,11 +197,15 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
         const int kpad = (int)ceil_div64(K, 16) * 16;
         if (g.Cout <= 32) {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 31) / 32, g.sh * g.sw);
-            hipLaunchKernelGGL((wide_gather_k<true, 1>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+            if (g_bf16) hipLaunchKernelGGL((wide_gather_k<true, 1, true>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
+            else hipLaunchKernelGGL((wide_gather_k<true, 1>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         } else {
             dim3 grid((unsigned)ceil_div64(npix, 64), (g.Cout + 63) / 64, g.sh * g.sw);
-            hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+            if (g_bf16) hipLaunchKernelGGL((wide_gather_k<true, 2, true>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
+                               c.B, g, act, slope, accumulate, kpad);
+            else hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         }
         VAE_LAUNCH_CHECK("wide_gather_k");
@@ -245,7 +254,8 @@ static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw,
         a.d_SHW = mk_fdiv((uint32_t)(SH * SW)); a.d_SW = mk_fdiv((uint32_t)SW);
         a.d_KK = mk_fdiv((uint32_t)(KH * KW)); a.d_KW = mk_fdiv((uint32_t)KW);
         dim3 grid((unsigned)wp.chunks, wp.gy, wp.gz);
-        hipLaunchKernelGGL(wide_wgrad_k, grid, dim3(WD_THREADS), 0, c.s, a);
+        if (g_bf16) hipLaunchKernelGGL(wide_wgrad_k<true>, grid, dim3(WD_THREADS), 0, c.s, a);
+        else hipLaunchKernelGGL(wide_wgrad_k<false>, grid, dim3(WD_THREADS), 0, c.s, a);
         VAE_LAUNCH_CHECK("wide_wgrad_k");
         if (part != nullptr) {
             const int64_t n = (int64_t)A * wp.NK;
@@ -536,7 +546,8 @@ static WgPlan plan_wgrad(int B, int Sc, int SH, int SW, int Gc, int GH, int GW, 
 
 template <int MT, int NT>
 static void launch_wgrad_inst(const Ctx& c, const WgArgs& wa, int grid, size_t bytes) {
-    hipLaunchKernelGGL((igemm_wgrad_k<MT, NT>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
+    if (g_bf16) hipLaunchKernelGGL((igemm_wgrad_k<MT, NT, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
+    else hipLaunchKernelGGL((igemm_wgrad_k<MT, NT>), dim3(grid), dim3(IG_THREADS), bytes, c.s, wa);
 }
 // kernels with <= WG_SMALL_T accumulator tiles fit two workgroups per CU; the fat ones only one, and their
 // per-workgroup reduction is expensive: fewer, longer-lived workgroups
@@ -601,6 +612,13 @@ static int conv_igemm_fits(const vae_op& op, int B) {
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     return plan_gather(f, B).SB >= 1 && plan_gather(d, B).SB >= 1 && w.SB >= 1 && g.sh <= 2 && g.sw <= 2;
 }
+
+extern "C" int vae_set_compute_dtype(int dtype) {
+    if (dtype != VAE_DTYPE_F32 && dtype != VAE_DTYPE_BF16) VAE_FAIL(VAE_EINVAL, "set_compute_dtype: unknown dtype %d", dtype);
+    g_bf16 = dtype == VAE_DTYPE_BF16;
+    return VAE_OK;
+}
+extern "C" int vae_get_compute_dtype(void) { return g_bf16 ? VAE_DTYPE_BF16 : VAE_DTYPE_F32; }
 
 extern "C" int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world) {
     if (fn == nullptr || world <= 1) {
@@ -710,7 +728,12 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const size_t bytes = (size_t)p.total * sizeof(float);
     const bool grad = a.in.mode >= TR_GRAD_BN;
     const int nd = gather_direct_nd(a.g, a.cls, a.ncls);
-#define IG_LAUNCH(NT, GR, ND) hipLaunchKernelGGL((igemm_gather_k<NT, 2, GR, ND>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a)
+    // (the ND > 0 instances compute on the vector ALU in fp32 whatever the compute dtype)
+#define IG_LAUNCH(NT, GR, ND)                                                                                                  \
+    do {                                                                                                                       \
+        if (g_bf16 && ND == 0) hipLaunchKernelGGL((igemm_gather_k<NT, 2, GR, 0, true>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a); \
+        else hipLaunchKernelGGL((igemm_gather_k<NT, 2, GR, ND>), dim3(grid), dim3(IG_THREADS), bytes, c.s, a);                 \
+    } while (0)
     if (a.g.Np > 16) {
         if (grad) IG_LAUNCH(2, true, 0); else IG_LAUNCH(2, false, 0);
     } else if (nd == 1) {
@@ -1028,8 +1051,13 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     }
     const size_t bytes = (size_t)(LIN_BM * a.Kp + a.KC * LIN_WS) * sizeof(float);
     dim3 grid((a.B + LIN_BM - 1) / LIN_BM, ny);
-    if (vec) hipLaunchKernelGGL(lin_fwd_k<true>, grid, dim3(LIN_THREADS), bytes, c.s, a);
-    else hipLaunchKernelGGL(lin_fwd_k<false>, grid, dim3(LIN_THREADS), bytes, c.s, a);
+    if (g_bf16) {
+        if (vec) hipLaunchKernelGGL((lin_fwd_k<true, true>), grid, dim3(LIN_THREADS), bytes, c.s, a);
+        else hipLaunchKernelGGL((lin_fwd_k<false, true>), grid, dim3(LIN_THREADS), bytes, c.s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((lin_fwd_k<true, false>), grid, dim3(LIN_THREADS), bytes, c.s, a);
+        else hipLaunchKernelGGL((lin_fwd_k<false, false>), grid, dim3(LIN_THREADS), bytes, c.s, a);
+    }
     VAE_LAUNCH_CHECK(what);
     return VAE_OK;
 }
@@ -1062,7 +1090,8 @@ static int flush_linear_wgrads(const Ctx& c) {
         m.l[i].first_block = blocks;
         blocks += m.l[i].gx * m.l[i].gy * m.l[i].gz;
     }
-    hipLaunchKernelGGL(lin_wgrad_k, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    if (g_bf16) hipLaunchKernelGGL(lin_wgrad_k<true>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    else hipLaunchKernelGGL(lin_wgrad_k<false>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
     m.n = 0;
     VAE_LAUNCH_CHECK("lin_wgrad_k");
     return VAE_OK;
@@ -1457,7 +1486,7 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
 }
 
 extern "C" int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat) {
-    if (ops == nullptr || n_ops < 6 || B < 1 || nflat < 1 || !sq_enabled()) return 0;
+    if (ops == nullptr || n_ops < 6 || B < 1 || nflat < 1 || g_bf16 || !sq_enabled()) return 0;
     static thread_local SqProgram sq;
     if (!sq_match(ops, n_ops, &sq) || !sq_plan(sq.d, B)) return 0;
     return sq_scratch_floats(sq.d, nflat);

@@ -19,8 +19,24 @@
 #define WD_THREADS 256
 #define WD_ST 17  // LDS row stride (floats)
 
+template <bool BF>
 __device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, int arow0, int brow0, int li, int lk,
                                              f32x4 (&acc)[2][2]) {
+    if constexpr (BF) {  // (igemm.h: bf16 compute mode) one MFMA per 16-column step; this lane's k-values: lk*4 + 0..3
+        s16x4 av[2], bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* ar = As + (arow0 + t * 16 + li) * WD_ST + lk * 4;
+            const float* br = Bs + (brow0 + t * 16 + li) * WD_ST + lk * 4;
+            av[t] = bf16_pack4(ar[0], ar[1], ar[2], ar[3]);
+            bv[t] = bf16_pack4(br[0], br[1], br[2], br[3]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = MFMA_BF16(av[t], bv[u], acc[t][u]);
+        return;
+    }
 #pragma unroll
     for (int k4 = 0; k4 < 16; k4 += 4) {
         float av[2], bv[2];
@@ -40,7 +56,7 @@ __device__ __forceinline__ void wd_mfma_step(const float* As, const float* Bs, i
 
 // CW = channel waves: the tile is 32*CW channels x 64 pixels (CW = 1 keeps layers with <= 32 output channels from
 // computing a half-empty 64-channel tile).  Wave layout: CW x (4/CW) waves, each 2 channel tiles x CW pixel tiles.
-template <bool TR, int CW>
+template <bool TR, int CW, bool BF = false>
 __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
                                                             ConvGeom g, int act, float slope, int accumulate,
@@ -152,6 +168,23 @@ __global__ __launch_bounds__(WD_THREADS) void wide_gather_k(const float* __restr
         if (s + 1 < nsteps) load_step((s + 1) * 16);  // in flight during the MFMAs below
         const float* Wb = Ws[s & 1];
         const float* Xb = Xs[s & 1];
+        if constexpr (BF) {
+            s16x4 av[2], bv[PXT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* r = Wb + (ch0 + t * 16 + li) * WD_ST + lk * 4;
+                av[t] = bf16_pack4(r[0], r[1], r[2], r[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < PXT; ++u) {
+                const float* r = Xb + (px0 + u * 16 + li) * WD_ST + lk * 4;
+                bv[u] = bf16_pack4(r[0], r[1], r[2], r[3]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < PXT; ++u) acc[t][u] = MFMA_BF16(av[t], bv[u], acc[t][u]);
+        } else
 #pragma unroll
         for (int k4 = 0; k4 < 16; k4 += 4) {
             float av[2], bv[PXT];
@@ -205,6 +238,7 @@ struct WideWgArgs {
     FastDiv d_SHW, d_SW, d_KK, d_KW;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(WD_THREADS) void wide_wgrad_k(WideWgArgs a) {
     __shared__ float Ss[2][64 * WD_ST];  // [a][pixel]
     __shared__ float Gs[2][64 * WD_ST];  // [(c,tap)][pixel]
@@ -273,7 +307,7 @@ __global__ __launch_bounds__(WD_THREADS) void wide_wgrad_k(WideWgArgs a) {
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         if (s + 1 < nsteps) load_step(r_begin + (int64_t)(s + 1) * 16);
-        wd_mfma_step(Ss[s & 1], Gs[s & 1], a_half * 32, n_half * 32, li, lk, acc);
+        wd_mfma_step<BF>(Ss[s & 1], Gs[s & 1], a_half * 32, n_half * 32, li, lk, acc);
         if (s + 1 < nsteps) store_step((s + 1) & 1);
         __syncthreads();
     }

@@ -117,7 +117,7 @@ class HipModule(nn.Module):
         return flat, sflat
 
     def compiled(self, B, training, key_extra=()):
-        key = (B, bool(training), torch.is_grad_enabled()) + tuple(key_extra)
+        key = (B, bool(training), torch.is_grad_enabled(), L.get_compute_dtype()) + tuple(key_extra)
         cache = self.__dict__.setdefault("_programs", {})
         sig = (tuple(self._param_off.values()), tuple(self._state_off.values()))
         if cache.get("sig") != sig:

@@ -138,6 +138,7 @@ class FusedTrainStep:
         self.model, self.opt, self.B, self.device = model, optimizer, B, torch.device(device)
         self.bce = model.elbo_bce if bce is None else bool(bce)
         self.group = optimizer.param_groups[0]
+        self.dtype = L.get_compute_dtype()  # the program (and a captured graph) keeps the kernels of this dtype
         flat, sflat = model.pack(self.device)
         plist = [p for _, p in model.named_parameters()]
         if len(optimizer.param_groups) != 1 or [id(p) for p in self.group["params"]] != [id(p) for p in plist]:
@@ -215,6 +216,9 @@ class FusedTrainStep:
             if x.shape != self.x.shape:
                 raise ValueError(f"fused step was built for batches {tuple(self.x.shape)}, got {tuple(x.shape)}")
             self.x.copy_(x, non_blocking=True)
+        if L.get_compute_dtype() != self.dtype:
+            raise L.VaeAmdError(f"this fused step was built under compute dtype {self.dtype}; "
+                                f"the current one is {L.get_compute_dtype()} (build a new stepper)")
         self._refresh_hyper()
         if self.use_graph:
             if self.graph is None or self._captured_inject != self.inject_eps:
@@ -251,7 +255,7 @@ def _fused_stepper(model, criterion_fn, optimizer, data):
     # full and the ragged last batch, and each keeps its program, workspace and hipGraph.  The flat parameter
     # buffer's address is part of the key, so a repack (model.cpu().cuda(), load of unpacked weights) starts afresh.
     flat, _ = model.pack(data.device)
-    key = (data.shape[0], id(optimizer), criterion_fn.elbo_bce, str(data.device), flat.data_ptr())
+    key = (data.shape[0], id(optimizer), criterion_fn.elbo_bce, str(data.device), flat.data_ptr(), L.get_compute_dtype())
     cache = model.__dict__.setdefault("_stepper", {})
     st = cache.get(key)
     if st is None:
