@@ -126,3 +126,74 @@ def test_wide_layer_gradients_are_bit_identical():
         torch.cuda.synchronize()
         outs.append(st.grads.clone())
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+def test_sample_from_data_batched_equals_pass_by_pass():
+    """utils.sample_from_data (utils.py:34-74): in eval mode the n stochastic passes of a batch run as one forward over
+    the batch repeated n times; the result must equal n separate passes with the same noise (and the reference's
+    formula evaluated by the CPU oracle on it)."""
+    import numpy as np
+    import vae_amd
+    from oracle import vae_oracle as O
+    from torch.utils.data import DataLoader
+    from vae_amd.train import slidingWindow
+    m, g = _model("multiscale_c3_l60")
+    m.eval()
+    torch.manual_seed(1)
+    t = torch.arange(150, dtype=torch.float32)
+    series = torch.stack([50 + 10 * torch.sin(t / 9 + c) + torch.randn(150) for c in range(3)])
+    loader = DataLoader(slidingWindow(series, 60), batch_size=32)     # 90 windows: 32, 32, 26
+    n, latent = 5, 15
+    T = 90
+    gen = torch.Generator().manual_seed(2)
+    eps = (torch.randn(n, T, 2 * latent, generator=gen), torch.randn(n, T, 2 * latent, generator=gen))
+    x, mu, logvar, z, x_rec, x_rec_mean = vae_amd.utils.sample_from_data(m, loader, n, latent, _eps=eps)
+    assert x.shape == (T, 3) and mu.shape == (T, 30) and x_rec.shape == (T, n * 3) and tuple(x_rec_mean.shape) == (T, 3)
+    # pass by pass through the oracle (eval mode: running statistics)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    windows = torch.stack([loader.dataset[i] for i in range(T)])
+    recs, zs = [], []
+    for j in range(n):
+        r = O.multiscale_forward(sd, windows, eps[0][j], training=False)
+        recs.append(r[0])
+        zs.append(O.reparam(r[1], r[2], eps[1][j]))
+        np.testing.assert_allclose(mu, r[1].numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(z, torch.stack(zs).mean(0).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(x_rec_mean.numpy(), torch.stack(recs).mean(0).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(x_rec, torch.stack(recs).permute(1, 0, 2).reshape(T, -1).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(x, windows[:, :, 0].numpy())
+
+
+def test_eval_forward_of_1d_models_runs_as_phases():
+    """Eval forward of a 1-D model at the benched batch: the whole-model path (6 launches, BatchNorm applied from the
+    running statistics in the consumer's prologue) against the per-layer program (~30 launches): same outputs, and not
+    slower end to end (measured 0.158 vs 0.205 ms per eager call at B = 4096; both are bound by the Python call path
+    around the launches, not by the GPU)."""
+    import os
+    import time
+    import vae_amd
+    B = 4096
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = 50 + 10 * torch.randn(B, 3, 60, device=DEV, generator=gen)
+    eps = torch.randn(B, 30, device=DEV, generator=gen)
+    outs, times = [], []
+    for seq in ("1", "0"):
+        os.environ["VAE_AMD_SEQ1D"] = seq
+        try:
+            m, _ = _model("multiscale_c3_l60")
+            m.eval()
+            with torch.no_grad():
+                out = m(x, eps=eps)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    out = m(x, eps=eps)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) / 50)
+            outs.append([o.clone() for o in out])
+        finally:
+            os.environ.pop("VAE_AMD_SEQ1D", None)
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3)
+    print(f"eval forward B={B}: phases {times[0] * 1e3:.3f} ms, per layer {times[1] * 1e3:.3f} ms")
+    assert times[0] <= 1.05 * times[1], times
