@@ -178,8 +178,10 @@ def test_bf16_single_conv_layer(geom):
     used.append(_either(prog.grad_view(work, xin, (cin, H, W)).cpu(), refs[0][1], refs[1][1], "input gradient"))
     used.append(_either(grads[:w.numel()].view(w.shape).cpu(), refs[0][2], refs[1][2], "weight gradient"))
     torch.testing.assert_close(grads[w.numel():].cpu(), refs[0][3], rtol=1e-3, atol=2e-5 * float(refs[0][3].abs().max()))
-    # the weight gradient is an MFMA kernel for every layer, so bf16 operands must have been what ran there
-    assert used[2], "weight gradient matched the fp32 reference: the bf16 instance did not run"
+    # the weight gradient is an MFMA kernel with bf16 instances for every layer except the single-channel outer ones
+    # (thin.h streams those in fp32 in both modes), so bf16 operands must have been what ran there
+    if cin > 1 and cout > 1:
+        assert used[2], "weight gradient matched the fp32 reference: the bf16 instance did not run"
 
 
 @pytest.mark.parametrize("K,N,B,act", [(288, 100, 70, True), (100, 15, 33, False), (15, 100, 129, True), (51, 37, 64, False)])

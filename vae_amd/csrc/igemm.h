@@ -121,9 +121,13 @@ struct IgArgs {
 };
 
 #ifdef IG_TIMERS  // diagnostic build only: phase stamps of workgroup 1 (wall clock, 10 ns ticks)
-#define IG_TDECL long long tm_[24]; int tn_ = 0
+#define IG_TDECL long long tm_[24]; int tn_ = 0; const long long ck0_ = clock64()
+#if IG_TIMERS == 2  // wave 0's own timeline: no barrier and no wait in the stamp
+#define IG_T() do { if (threadIdx.x == 0 && blockIdx.x == 1 && tn_ < 24) tm_[tn_++] = wall_clock64(); } while (0)
+#else
 #define IG_T() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 1 && tn_ < 24) tm_[tn_++] = wall_clock64(); } while (0)
-#define IG_TPRINT(name) do { if (threadIdx.x == 0 && blockIdx.x == 1) { printf("%s", name); for (int q_ = 1; q_ < tn_; ++q_) printf(" %lld", (tm_[q_] - tm_[q_-1]) * 10); printf(" ns\n"); } } while (0)
+#endif
+#define IG_TPRINT(name) do { if (threadIdx.x == 0 && blockIdx.x == 1) { printf("%s", name); for (int q_ = 1; q_ < tn_; ++q_) printf(" %lld", (tm_[q_] - tm_[q_-1]) * 10); printf(" ns; shader clock %.0f MHz\n", (double)(clock64() - ck0_) / ((double)(wall_clock64() - tm_[0]) * 10e-3)); } } while (0)
 #else
 #define IG_TDECL
 #define IG_T()
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
         }
         }  // chunk >= 0
+        IG_T();
         lds_barrier();  // lout is complete, lin is free
         IG_T();
         if (nx < a.nchunks) {
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 ig_stage(a.in, cin, lin, (int64_t)cs0 * CHW, csb, g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w,
                          g.d_CHW, g.d_HW, g.d_W);
         }
+        IG_T();
         if (chunk < 0) continue;
 
         // ---- write the chunk out (contiguous in global memory) + per-channel sums
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     IG_T();
 #ifdef IG_TIMERS
     if (threadIdx.x == 0 && blockIdx.x == 1)
-        printf("gather<%d,%d,%d,%d> Cin %d N %d H %d OH %d SB %d chunks %d grid %d: setup | per chunk: top stage mfma | out ...", NT, TI, (int)GRAD, ND,
+        printf("gather<%d,%d,%d,%d> Cin %d N %d H %d OH %d SB %d chunks %d grid %d: setup | per round: [top barrier] tiles, barrier, stage(next), copy-out+stats ...", NT, TI, (int)GRAD, ND,
                g.Cin, g.N, g.H, g.OH, a.SB, a.nchunks, (int)gridDim.x);
 #endif
     IG_TPRINT("");

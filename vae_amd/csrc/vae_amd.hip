@@ -17,6 +17,7 @@
 #include "igemm.h"
 #include "lin.h"
 #include "wide.h"
+#include "thin.h"
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
@@ -602,6 +603,56 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
     return VAE_OK;
 }
 
+// ---- thin outer layers (thin.h): first convolution 1 -> 8 and last transposed convolution 8 -> 1, 3x3 stride 2 pad 1 ----
+#define TH_C 8
+#define TH_MAX_GRID 2048
+static int thin_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VAE_AMD_THIN");
+        v = (e != nullptr && *e) ? atoi(e) != 0 : 1;
+    }
+    return v;
+}
+// 1: conv (Cin = 1 -> TH_C channels, output H x W = OH x OW); 2: transposed (TH_C channels H x W -> 1 channel 2H x 2W); 0: no
+static int thin_kind(const ConvGeom& g, int T) {
+    if (!thin_enabled() || g.KH != 3 || g.KW != 3 || g.sh != 2 || g.sw != 2 || g.ph != 1 || g.pw != 1) return 0;
+    // (the single-channel image is fetched as one float4 per thread: rows a multiple of 4, at most 1024 elements)
+    if (!T && g.Cin == 1 && g.Cout == TH_C && g.H == 2 * g.OH && g.W == 2 * g.OW && g.OH * g.OW <= TH_MAX_HW &&
+        (g.W & 3) == 0 && g.H * g.W <= 4 * TH_THREADS)
+        return 1;
+    if (T && g.Cout == 1 && g.Cin == TH_C && g.OH == 2 * g.H && g.OW == 2 * g.W && g.H * g.W <= TH_MAX_HW &&
+        (g.OW & 3) == 0 && g.OH * g.OW <= 4 * TH_THREADS)
+        return 2;
+    return 0;
+}
+static int thin_grid(int B) {
+    static int cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("VAE_THIN_GRID");
+        cap = (e != nullptr && atoi(e) > 0) ? atoi(e) : 512;  // two workgroups per CU measured best (256: 0.672, 512: 0.652, 1024: 0.658 ms/step)
+        if (cap > TH_MAX_GRID) cap = TH_MAX_GRID;
+    }
+    return B < cap ? B : cap;
+}
+static int64_t thin_part_floats(int B) { return (int64_t)(B < TH_MAX_GRID ? B : TH_MAX_GRID) * (10 * TH_C); }
+static size_t thin_lds_bytes(int H, int W, int kernel) {  // kernel: 0 conv fwd, 1 conv wgrad, 2 convT fwd, 3 convT bwd
+    const int img = (2 * H + 1) * (2 * W + 1);
+    switch (kernel) {
+        case 0: return (size_t)(2 * img) * sizeof(float);
+        case 1: return (size_t)(2 * img + 8 * TH_C + 1024 + TH_THREADS * TH_MM_STRIDE + 16) * sizeof(float);
+        case 2: return (size_t)(2 * TH_C * (H + 1) * (W + 1) + 8 * TH_C) * sizeof(float);
+        default: return (size_t)(2 * img + 8 * TH_C + 1024 + TH_THREADS * TH_MM_STRIDE + 16) * sizeof(float);
+    }
+}
+// the activation is a template argument of the thin kernels
+#define THIN_LAUNCH(KERNEL, ACTV, GRID, BYTES, STREAM, ARGS)                                                                     \
+    do {                                                                                                                       \
+        if ((ACTV) == VAE_ACT_SIGMOID) hipLaunchKernelGGL((KERNEL<TH_C, VAE_ACT_SIGMOID>), dim3(GRID), dim3(TH_THREADS), BYTES, STREAM, ARGS); \
+        else if ((ACTV) == VAE_ACT_LEAKY) hipLaunchKernelGGL((KERNEL<TH_C, VAE_ACT_LEAKY>), dim3(GRID), dim3(TH_THREADS), BYTES, STREAM, ARGS); \
+        else hipLaunchKernelGGL((KERNEL<TH_C, VAE_ACT_NONE>), dim3(GRID), dim3(TH_THREADS), BYTES, STREAM, ARGS);             \
+    } while (0)
+
 static int conv_igemm_fits(const vae_op& op, int B) {
     const ConvGeom g = geom_of(op);
     const int T = op.kind == VAE_OP_CONVT;
@@ -655,7 +706,9 @@ extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
     }
     const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
-    return w.SB < 1 ? 0 : wgrad_part_floats(w, B);
+    if (w.SB < 1) return 0;
+    const int64_t need = wgrad_part_floats(w, B), thin = thin_kind(g, T) != 0 ? thin_part_floats(B) : 0;
+    return need > thin ? need : thin;
 }
 
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
@@ -784,6 +837,19 @@ static int conv_forward_fused(const Ctx& c, const vae_op& op, int training) {
     a.act = op.act; a.slope = op.f[0];
     a.ep_mode = EP_PLAIN; a.ep_y = nullptr; a.ep_coef = nullptr; a.ep_relu = 0;
     a.slab = nullptr;
+    const int thin = op.r[8] < 0 ? thin_kind(g, T) : 0;  // (the thin kernels take no BatchNorm statistics of their output)
+    if (thin != 0 && (thin == 2 || op.r[7] < 0)) {
+        if (!ok) return VAE_EINVAL;
+        ThinArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in = a.in; t.w = a.w; t.bias = a.bias; t.out = a.out; t.B = c.B; t.act = op.act; t.slope = op.f[0];
+        t.H = thin == 1 ? g.OH : g.H; t.W = thin == 1 ? g.OW : g.W;
+        t.d_W = mk_fdiv((uint32_t)t.W); t.d_W4 = mk_fdiv((uint32_t)(2 * t.W / 4));
+        if (thin == 1) THIN_LAUNCH(thin_conv_fwd_k, op.act, thin_grid(c.B), thin_lds_bytes(t.H, t.W, 0), c.s, t);
+        else THIN_LAUNCH(thin_convT_fwd_k, op.act, thin_grid(c.B), thin_lds_bytes(t.H, t.W, 2), c.s, t);
+        VAE_LAUNCH_CHECK("thin conv forward");
+        return VAE_OK;
+    }
     if (op.r[8] >= 0 && training) {
         const IgPlan p = plan_gather(a.g, c.B);
         if (p.SB >= 1 && slab_ok(c, op.r[6], (c.B + p.SB - 1) / p.SB, g.Cout)) return VAE_EINVAL;
@@ -823,6 +889,43 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), g.Cout, "conv.db", &ok);
     float* dx = resolve_opt(c, op.r[2], nin, "conv.din", &ok);
     if (!ok) return VAE_EINVAL;
+
+    {   // thin outer layers: one streaming kernel for the whole backward of the layer (thin.h)
+        const int thin = op.r[8] < 0 ? thin_kind(g, T) : 0;
+        if ((thin == 1 && dx == nullptr && op.r[7] < 0) || thin == 2) {
+            ThinArgs t;
+            memset(&t, 0, sizeof(t));
+            t.in = tin; t.g = tg; t.w = w; t.B = c.B; t.want_bias = db != nullptr;
+            t.H = thin == 1 ? g.OH : g.H; t.W = thin == 1 ? g.OW : g.W;
+            t.d_W = mk_fdiv((uint32_t)t.W); t.d_W4 = mk_fdiv((uint32_t)(2 * t.W / 4));
+            t.slope = op.f[0];
+            const int grid = thin_grid(c.B);
+            const int rowlen = thin == 1 ? 10 * TH_C : 9 * TH_C + 1;
+            t.part = resolve(c, op.r[10], (int64_t)grid * rowlen, "conv.wgrad_partials", &ok);
+            if (!ok) return VAE_EINVAL;
+            if (thin == 1) {
+                THIN_LAUNCH(thin_conv_wgrad_k, op.act, grid, thin_lds_bytes(t.H, t.W, 1), c.s, t);
+            } else {
+                t.out = dx;
+                if (dx != nullptr && op.r[7] >= 0) {  // the producer's BatchNorm is virtual: its backward sums, one row per workgroup
+                    if (slab_ok(c, op.r[6], grid, g.Cin)) return VAE_EINVAL;
+                    t.slab = resolve(c, op.r[6], 4 * g.Cin, "conv.slab", &ok);
+                    t.ep_coef = tin.coef; t.ep_relu = tin.relu;
+                    if (!ok) return VAE_EINVAL;
+                }
+                THIN_LAUNCH(thin_convT_bwd_k, op.act, grid, thin_lds_bytes(t.H, t.W, 3), c.s, t);
+                if (t.slab != nullptr) c.last_blocks = grid;
+            }
+            VAE_LAUNCH_CHECK("thin conv backward");
+            if (c.wg_fin.n == WG_FIN_MAX_LAYERS && (rc = flush_wgrad_finalize(c)) != VAE_OK) return rc;
+            WgFinLayer& F = c.wg_fin.l[c.wg_fin.n++];
+            memset(&F, 0, sizeof(F));
+            F.part = t.part; F.dw = dw; F.dbias = db; F.nrows = grid; F.NT = 1; F.T = 0;
+            F.Sc = TH_C; F.NK = 9; F.C = thin == 1 ? TH_C : 1;
+            F.plain = 1; F.stride = rowlen; F.ncols = 9 * TH_C + (db != nullptr ? F.C : 0);
+            return VAE_OK;
+        }
+    }
 
     // 1) weight (+bias) gradient
     WgArgs wa;
