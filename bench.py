@@ -162,7 +162,7 @@ def pmc_traffic(model_name, kernel, B):
 
 
 def roofline_mnist(stepper, iters, bf16=False):
-    """Dominant kernel igemm_gather_k<1, 2, false, 0> (the forward implicit-GEMM gather on MFMA tiles of the conv /
+    """Dominant kernel igemm_gather_k<1, 2, false, 0, BF> (the forward implicit-GEMM gather on MFMA tiles of the conv /
     transposed-conv layers with <= 16 output channels: conv2, convT1, convT2; the largest line of
     profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch stream
     (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
@@ -190,7 +190,7 @@ def roofline_mnist(stepper, iters, bf16=False):
     avg_us = sum(tot_ms) / iters / len(sel) * 1e3
     avg_bytes = sum(b for _, b in sel) / len(sel)
     achieved = avg_bytes / (avg_us * 1e-6) / 1e9
-    kernel = "igemm_gather_k<1, 2, false, 0, true>" if bf16 else "igemm_gather_k<1, 2, false, 0>"
+    kernel = "igemm_gather_k<1, 2, false, 0, true>" if bf16 else "igemm_gather_k<1, 2, false, 0, false>"
     traffic, src = pmc_traffic("mnist", kernel, stepper.B)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel,
