@@ -473,3 +473,233 @@ __global__ __launch_bounds__(TH_THREADS) void thin_convT_bwd_k(ThinArgs a) {
         sl[3] = 0.f;
     }
 }
+
+// ================================================================================================================
+// Mid-size layers (8 <-> 16 channels on 14x14 <-> 7x7 maps: conv2 / convT2 of the notebook model), same recipe: a
+// 256-thread workgroup streams whole samples, loads two rounds ahead in a second register set, branch-free
+// transforms, one LDS-only barrier per round, several workgroups per CU.
+//
+// mid_wgrad_k<MT, NT, S_GRAD, ACT>: weight + bias gradient
+//   dw[a][c][kh][kw] = sum_{b,oh,ow} S[b,a,oh,ow] * G[b,c,oh*sh-ph+kh,ow*sw-pw+kw]
+// (Conv: S = d(pre-activation) [Cout] on the small grid, G = layer input [Cin]; ConvT: S = layer input, G = d(pre-act)).
+// Per sample the product is [Sc x P] x [P x Gc*KK] with P = SH*SW pixels as the MFMA's K: the four waves split the
+// k-steps (4 pixels each), every wave keeps all MT x NT accumulator tiles for the whole kernel; A = S[a][pixel] from
+// the LDS copy of S, B = G gathered from the zero-haloed LDS image at (pixel base of the k-step) + (lane constant
+// (c, tap) offset); both index sets live in registers.  One cross-wave reduction per workgroup at the end; the partial
+// row has the layout of igemm_wgrad_k's (accumulator-tile order, bias sums behind), so wgrad_finalize_k serves both.
+// S_GRAD: S is the gradient-type tensor (then G is the input-type one), else the other way round.
+struct MidWgArgs {
+    TensorIn S, G;
+    float* part;      // [grid][MT*NT*256 + 64]
+    int want_bias;
+    int B;
+    int Sc, SH, SW;   // S: channels, small grid
+    int Gc, GH, GW;   // G: channels, big grid
+    int KH, KW, sh, sw, ph, pw;
+    int Hp, Wp;       // padded G image (halo = ph, pw on the low side)
+    float slope;
+    FastDiv dS_HW, dS_W, dG_HW, dG_W, d_KK, d_KW;
+};
+#define MID_NS 4   // S elements per thread: Sc*SH*SW <= 1024
+#define MID_NG 7   // G elements per thread: Gc*GH*GW <= 1792
+#define MID_KSW 4  // k-steps per wave: SH*SW <= 64
+
+template <int MT, int NT, bool S_GRAD, int ACT>
+__global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int SHW = a.SH * a.SW, GHW = a.GH * a.GW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW, NK = a.Gc * KK;
+    const int nS = a.Sc * SHW, nG = a.Gc * GHW, imgG = a.Gc * HpWp;
+    const TensorIn& tin = S_GRAD ? a.G : a.S;   // the input-type tensor
+    const TensorIn& tgr = S_GRAD ? a.S : a.G;   // the gradient-type tensor
+    const int Cin_t = S_GRAD ? a.Gc : a.Sc, Cgr_t = S_GRAD ? a.Sc : a.Gc;
+    // LDS: [2][nS] S tiles, [2][imgG] G images, input coefs [4*Cin_t + 4], gradient coefs [4*Cgr_t], bias scratch / reduce
+    float* lS[2] = {smem, smem + nS};
+    float* lG[2] = {smem + 2 * nS, smem + 2 * nS + imgG};
+    float* cin = smem + 2 * nS + 2 * imgG;
+    float* cgr = cin + 4 * Cin_t + 4;
+    const int g = gridDim.x, last = a.B - 1;
+
+    // staged elements of this thread: S slot j -> element tid + 256 j (channel fixed per slot), same for G
+    float sA[MID_NS], sB[MID_NS], sAy[S_GRAD ? MID_NS : 1], sBy[S_GRAD ? MID_NS : 1];
+    float gA[MID_NG], gB[MID_NG], gAy[S_GRAD ? 1 : MID_NG], gBy[S_GRAD ? 1 : MID_NG];
+    auto load = [&](int s, float (&sv)[MID_NS], float (&sy)[S_GRAD ? MID_NS : 1], float (&gv)[MID_NG],
+                    float (&gy)[S_GRAD ? 1 : MID_NG]) {
+        s = min(s, last);
+        const float* ps = a.S.src + (int64_t)s * nS;
+        const float* pg = a.G.src + (int64_t)s * nG;
+#pragma unroll
+        for (int j = 0; j < MID_NS; ++j) {
+            const int e = min(tid + 256 * j, nS - 1);
+            sv[j] = ps[e];
+            if (S_GRAD) sy[j] = a.S.src2[(int64_t)s * nS + e];
+        }
+#pragma unroll
+        for (int j = 0; j < MID_NG; ++j) {
+            const int e = min(tid + 256 * j, nG - 1);
+            gv[j] = pg[e];
+            if (!S_GRAD) gy[j] = a.G.src2[(int64_t)s * nG + e];
+        }
+    };
+    load(blockIdx.x, sA, sAy, gA, gAy);
+    load(blockIdx.x + g, sB, sBy, gB, gBy);
+
+    // ---- once per workgroup
+    for (int e = tid; e < 2 * imgG; e += TH_THREADS) lG[0][e] = 0.f;  // the halo stays zero
+    for (int e = tid; e < 4 * Cin_t; e += TH_THREADS) {
+        float v = (e >= 2 * Cin_t && e < 3 * Cin_t) ? 1.f : 0.f;
+        if (tin.mode == TR_BN) v = tin.coef[e];
+        cin[e] = v;
+    }
+    if (tid == 0) cin[4 * Cin_t] = (tin.mode == TR_BN && tin.relu) ? 0.f : -__builtin_inff();
+    for (int e = tid; e < 4 * Cgr_t; e += TH_THREADS) {
+        const int q = e / Cgr_t, c = e - q * Cgr_t;
+        float v = q == 1 ? 1.f : 0.f;
+        if (tgr.mode == TR_GRAD_BN) v = tgr.coef[(q == 0 ? 0 : 3 + q) * Cgr_t + c];
+        cgr[e] = v;
+    }
+    // per-slot constants: channel and LDS destination
+    int sch[MID_NS], gch[MID_NG], gdst[MID_NG];
+#pragma unroll
+    for (int j = 0; j < MID_NS; ++j) sch[j] = (int)fdiv((uint32_t)min(tid + 256 * j, nS - 1), a.dS_HW);
+#pragma unroll
+    for (int j = 0; j < MID_NG; ++j) {
+        const int e = min(tid + 256 * j, nG - 1);
+        const int c = (int)fdiv((uint32_t)e, a.dG_HW), pos = e - c * GHW;
+        const int ih = (int)fdiv((uint32_t)pos, a.dG_W), iw = pos - ih * a.GW;
+        gch[j] = c;
+        gdst[j] = c * HpWp + (ih + a.ph) * a.Wp + iw + a.pw;
+    }
+    // MFMA index sets: this wave's k-steps are wid, wid + 4, ...; pixel of a step for this lane: 4 * step + lk
+    int pS[MID_KSW], pG[MID_KSW];
+    float pOn[MID_KSW];
+#pragma unroll
+    for (int q = 0; q < MID_KSW; ++q) {
+        const int p = 4 * (wid + 4 * q) + lk;
+        const bool on = p < SHW;
+        const int oh = (int)fdiv((uint32_t)(on ? p : 0), a.dS_W), ow = (on ? p : 0) - oh * a.SW;
+        pS[q] = on ? p : 0;
+        pG[q] = oh * a.sh * a.Wp + ow * a.sw;
+        pOn[q] = on ? 1.f : 0.f;
+    }
+    int moff[MT], koffN[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) moff[mt] = min(mt * 16 + li, a.Sc - 1) * SHW;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(nt * 16 + li, NK - 1);
+        const int c = (int)fdiv((uint32_t)n, a.d_KK), tap = n - c * KK;
+        const int kh = (int)fdiv((uint32_t)tap, a.d_KW), kw = tap - kh * a.KW;
+        koffN[nt] = c * HpWp + kh * a.Wp + kw;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int NB = S_GRAD ? MID_NS : MID_NG;  // bias partials: one per gradient slot (its channel is fixed)
+    float bacc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bacc[j] = 0.f;
+    lds_barrier();
+    const float thr = cin[4 * Cin_t];
+
+    // transform + store one sample's registers into buffer b; the gradient values also feed the bias partials
+    auto store = [&](int b, int s, const float (&sv)[MID_NS], const float (&sy)[S_GRAD ? MID_NS : 1], const float (&gv)[MID_NG],
+                     const float (&gy)[S_GRAD ? 1 : MID_NG]) {
+        const float live = s <= last ? 1.f : 0.f;
+        float so[MID_NS], go[MID_NG];
+#pragma unroll
+        for (int j = 0; j < MID_NS; ++j) {
+            const int c = sch[j];
+            if (S_GRAD) {
+                const float y = sy[j];
+                so[j] = fmaf(cgr[Cgr_t + c], sv[j], fmaf(cgr[2 * Cgr_t + c], y - cgr[c], cgr[3 * Cgr_t + c])) * th_act_grad<ACT>(y, a.slope);
+            } else {
+                so[j] = fmaxf(fmaf(sv[j] - cin[c], cin[2 * Cin_t + c], cin[3 * Cin_t + c]), thr);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MID_NG; ++j) {
+            const int c = gch[j];
+            if (!S_GRAD) {
+                const float y = gy[j];
+                go[j] = fmaf(cgr[Cgr_t + c], gv[j], fmaf(cgr[2 * Cgr_t + c], y - cgr[c], cgr[3 * Cgr_t + c])) * th_act_grad<ACT>(y, a.slope);
+            } else {
+                go[j] = fmaxf(fmaf(gv[j] - cin[c], cin[2 * Cin_t + c], cin[3 * Cin_t + c]), thr);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MID_NS; ++j) {
+            const bool in = tid + 256 * j < nS;
+            if (in) lS[b][tid + 256 * j] = so[j];
+            if (S_GRAD) bacc[j] += in ? so[j] * live : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < MID_NG; ++j) {
+            const bool in = tid + 256 * j < nG;
+            if (in) lG[b][gdst[j]] = go[j];
+            if (!S_GRAD) bacc[j] += in ? go[j] * live : 0.f;
+        }
+    };
+    auto compute = [&](int b, int s) {
+        if (s > last) return;
+        const float* S = lS[b];
+        const float* G = lG[b];
+#pragma unroll
+        for (int q = 0; q < MID_KSW; ++q) {
+            if (4 * (wid + 4 * q) >= SHW) break;  // (wave-uniform)
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = S[moff[mt] + pS[q]] * pOn[q];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = G[pG[q] + koffN[nt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    store(0, blockIdx.x, sA, sAy, gA, gAy);
+    load(blockIdx.x + 2 * g, sA, sAy, gA, gAy);
+    for (int s = blockIdx.x; s <= last; s += 2 * g) {
+        lds_barrier();  // buffer 0 is complete, buffer 1 is free
+        compute(0, s);
+        store(1, s + g, sB, sBy, gB, gBy);
+        load(s + 3 * g, sB, sBy, gB, gBy);
+        lds_barrier();
+        compute(1, s + g);
+        store(0, s + 2 * g, sA, sAy, gA, gAy);
+        load(s + 4 * g, sA, sAy, gA, gAy);
+    }
+
+    // ---- cross-wave reduction (the staging buffers are dead) and the partial row
+    __syncthreads();
+    constexpr int TE = MT * NT * 256;
+    float* red = smem;  // [4][TE] (the host sizes the dynamic LDS for it)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid * TE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    __syncthreads();
+    float* row = a.part + (int64_t)blockIdx.x * (TE + 64);
+    for (int i = tid; i < TE; i += TH_THREADS) row[i] = (red[i] + red[TE + i]) + (red[2 * TE + i] + red[3 * TE + i]);
+    __syncthreads();
+    // bias gradient: every slot's partial goes to its element's place, then one thread per channel adds the plane
+    if (a.want_bias) {
+        const int nB = S_GRAD ? nS : nG, HWb = S_GRAD ? SHW : GHW, Cb = S_GRAD ? a.Sc : a.Gc;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (tid + 256 * j < nB) red[tid + 256 * j] = bacc[j];
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+            if (tid < Cb)
+                for (int i = 0; i < HWb; ++i) t += red[tid * HWb + i];
+            row[TE + tid] = t;
+        }
+    } else if (tid < 64) {
+        row[TE + tid] = 0.f;
+    }
+}

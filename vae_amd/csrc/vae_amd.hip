@@ -603,6 +603,29 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
     return VAE_OK;
 }
 
+// ---- streaming weight gradient of the mid-size layers (thin.h: mid_wgrad_k<1, 5>) ----
+#define MID_MAX_GRID 1024
+static int mid_grid(int B) {
+    static int cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("VAE_MID_GRID");
+        cap = (e != nullptr && atoi(e) > 0) ? atoi(e) : 512;  // two workgroups per CU (the kernel holds ~210 registers)
+        if (cap > MID_MAX_GRID) cap = MID_MAX_GRID;
+    }
+    return B < cap ? B : cap;
+}
+// S: Sc channels on SH x SW, G: Gc channels on GH x GW (roles as in igemm_wgrad_k)
+static bool mid_wgrad_ok(int Sc, int SH, int SW, int Gc, int GH, int GW, int KH, int KW, int MT, int NT) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("VAE_AMD_MID");
+        on = (e != nullptr && *e) ? atoi(e) != 0 : 1;
+    }
+    return on && MT == 1 && NT == 5 && Sc <= 16 && SH * SW <= 16 * MID_KSW && Sc * SH * SW <= 256 * MID_NS &&
+           Gc * GH * GW <= 256 * MID_NG && Gc * KH * KW <= 80;
+}
+static int64_t mid_part_floats(int B, int T) { return (int64_t)(B < MID_MAX_GRID ? B : MID_MAX_GRID) * (T * 256 + 64); }
+
 // ---- thin outer layers (thin.h): first convolution 1 -> 8 and last transposed convolution 8 -> 1, 3x3 stride 2 pad 1 ----
 #define TH_C 8
 #define TH_MAX_GRID 2048
@@ -707,8 +730,12 @@ extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
     const WgPlan w = T ? plan_wgrad(B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw)
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     if (w.SB < 1) return 0;
-    const int64_t need = wgrad_part_floats(w, B), thin = thin_kind(g, T) != 0 ? thin_part_floats(B) : 0;
-    return need > thin ? need : thin;
+    int64_t need = wgrad_part_floats(w, B);
+    const bool mid_ok = T ? mid_wgrad_ok(g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, w.MT, w.NT)
+                          : mid_wgrad_ok(g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, w.MT, w.NT);
+    const int64_t thin = thin_kind(g, T) != 0 ? thin_part_floats(B) : 0, mid = mid_ok ? mid_part_floats(B, w.MT * w.NT) : 0;
+    if (thin > need) need = thin;
+    return mid > need ? mid : need;
 }
 
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
@@ -952,8 +979,42 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     wa.d_bC = mk_fdiv(wa.bias_from_S ? wa.Sc : wa.Gc);
     wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
     wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
-    rc = launch_wgrad(c, wa, wp, dw, db);
-    if (rc) return rc;
+    if (!g_bf16 && mid_wgrad_ok(wa.Sc, wa.SH, wa.SW, wa.Gc, wa.GH, wa.GW, g.KH, g.KW, wp.MT, wp.NT) &&
+        (op.act == VAE_ACT_NONE || op.act == VAE_ACT_LEAKY)) {
+        MidWgArgs m;
+        memset(&m, 0, sizeof(m));
+        m.S = wa.S; m.G = wa.G; m.want_bias = db != nullptr; m.B = c.B;
+        m.Sc = wa.Sc; m.SH = wa.SH; m.SW = wa.SW; m.Gc = wa.Gc; m.GH = wa.GH; m.GW = wa.GW;
+        m.KH = g.KH; m.KW = g.KW; m.sh = g.sh; m.sw = g.sw; m.ph = g.ph; m.pw = g.pw; m.Hp = wp.Hp; m.Wp = wp.Wp;
+        m.slope = op.f[0];
+        m.dS_HW = mk_fdiv(wa.SH * wa.SW); m.dS_W = mk_fdiv(wa.SW);
+        m.dG_HW = mk_fdiv(wa.GH * wa.GW); m.dG_W = mk_fdiv(wa.GW);
+        m.d_KK = mk_fdiv(g.KH * g.KW); m.d_KW = mk_fdiv(g.KW);
+        const int grid = mid_grid(c.B);
+        const int TE = wp.MT * wp.NT * 256;
+        m.part = resolve(c, op.r[10], (int64_t)grid * (TE + 64), "conv.wgrad_partials", &ok);
+        if (!ok) return VAE_EINVAL;
+        const int nS = wa.Sc * wa.SH * wa.SW, imgG = wa.Gc * wp.Hp * wp.Wp;
+        int fl = 2 * nS + 2 * imgG + 4 * (wa.Sc + wa.Gc) + 8;
+        if (fl < 4 * TE) fl = 4 * TE;
+        const size_t bytes = (size_t)fl * sizeof(float);
+        if (!T) {  // Conv: S is the gradient
+            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<1, 5, true, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
+            else hipLaunchKernelGGL((mid_wgrad_k<1, 5, true, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
+        } else {
+            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<1, 5, false, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
+            else hipLaunchKernelGGL((mid_wgrad_k<1, 5, false, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
+        }
+        VAE_LAUNCH_CHECK("mid_wgrad_k");
+        if (c.wg_fin.n == WG_FIN_MAX_LAYERS && (rc = flush_wgrad_finalize(c)) != VAE_OK) return rc;
+        WgFinLayer& L = c.wg_fin.l[c.wg_fin.n++];
+        L.part = m.part; L.dw = dw; L.dbias = db; L.nrows = grid; L.NT = wp.NT; L.T = wp.MT * wp.NT;
+        L.Sc = wa.Sc; L.NK = wa.Gc * g.KH * g.KW; L.C = wa.bias_from_S ? wa.Sc : wa.Gc;
+        L.plain = 0; L.stride = L.T * 256 + 64; L.ncols = L.stride;
+    } else {
+        rc = launch_wgrad(c, wa, wp, dw, db);
+        if (rc) return rc;
+    }
 
     // 2) input gradient
     if (dx == nullptr) return VAE_OK;
