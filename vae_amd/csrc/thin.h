@@ -703,3 +703,212 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
         row[TE + tid] = 0.f;
     }
 }
+
+// mid_conv_k<GRADIN, EPBN, ACT>: plain (non-transposed) gather of a mid-size layer: Conv forward (conv2) and ConvT input
+// gradient (convT2).  One sample per round; the input goes through a workgroup-shared zero-haloed LDS image
+// (double-buffered, two rounds of loads in flight); wave w owns the 16-pixel tile w of the sample's <= 64 output pixels
+// and keeps its 18 k-steps of weights (A operand) and im2col offsets in registers, so a tile is 18 x (ds_read +
+// v_mfma_f32_16x16x4_f32).  Results leave from the accumulators: D row = channel lk*4 + r, column = pixel li.
+//   GRADIN: the input is a gradient: (ga*g + gb*(y - mean) + gc) * act'(y) on load (ACT = that layer's activation)
+//   EPBN  : backward through the producer's virtual BatchNorm (+ReLU): mask, and its two sums per channel (slab rows
+//           {sum g, sum g*xhat}); else bias + activation (ACT) and, with a slab, forward statistics
+//           {pivot = bias, sum(y-p), sum((y-p)^2), n}.  One slab row per workgroup.
+// Uses IgArgs (igemm.h) for the geometry, tensors and epilogue description; its chunk/LDS/class fields are ignored.
+#define MIDC_KS 18  // Cin * KH * KW <= 72
+#define MIDC_NE 7   // Cin * H * W <= 1792
+template <bool GRADIN, bool EPBN, int ACT>
+__global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const IgGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int HW = g.H * g.W, CHW = g.Cin * HW, HpWp = g.Hp * g.Wp, OHW = g.OH * g.OW, KK = g.KH * g.KW, K = g.Cin * KK;
+    const int imgN = g.Cin * HpWp;
+    float* img[2] = {smem, smem + imgN};
+    float* cin = smem + 2 * imgN;                 // input coefficients [4 * Cin + 4]
+    float* cep = cin + 4 * g.Cin + 4;             // EPBN: producer BatchNorm [4 * N + 4] (mean, rstd, scale, beta, thr)
+    float* red = cep + 4 * g.N + 4;               // [4][16][2] + [4]
+    const int G = gridDim.x, last = a.B - 1;
+
+    float vA[MIDC_NE], vB[MIDC_NE], yA[GRADIN ? MIDC_NE : 1], yB[GRADIN ? MIDC_NE : 1];
+    float eA[EPBN ? 4 : 1], eB[EPBN ? 4 : 1];  // EPBN: the producer's outputs at this lane's four (channel, pixel) results
+    const int p_out = wid * 16 + li;           // this lane's output pixel
+    const bool p_ok = p_out < OHW;
+    auto load = [&](int s, float (&v)[MIDC_NE], float (&y)[GRADIN ? MIDC_NE : 1], float (&e)[EPBN ? 4 : 1]) {
+        s = min(s, last);
+        // (opaque thread index: otherwise the optimiser hoists every slot's 64-bit address out of the round loop,
+        // once per inlined copy of this lambda, into ~100 registers)
+        const int t0 = (int)opaque_tid();
+        const float* src = a.in.src + (int64_t)s * CHW;
+        const float* src2 = GRADIN ? a.in.src2 + (int64_t)s * CHW : nullptr;
+#pragma unroll
+        for (int j = 0; j < MIDC_NE; ++j) {
+            const int i = min(t0 + 256 * j, CHW - 1);
+            v[j] = src[i];
+            if (GRADIN) y[j] = src2[i];
+        }
+        if (EPBN) {
+            const float* py = a.ep_y + (int64_t)s * g.N * OHW + (p_ok ? p_out : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = py[min(lk * 4 + r, g.N - 1) * OHW];
+        }
+    };
+    load(blockIdx.x, vA, yA, eA);
+    load(blockIdx.x + G, vB, yB, eB);
+
+    // ---- once per workgroup
+    for (int e = tid; e < 2 * imgN; e += TH_THREADS) smem[e] = 0.f;  // the halo stays zero
+    if (GRADIN) {
+        for (int e = tid; e < 4 * g.Cin; e += TH_THREADS) {
+            const int q = e / g.Cin, c = e - q * g.Cin;
+            float v = q == 1 ? 1.f : 0.f;
+            if (a.in.mode == TR_GRAD_BN) v = a.in.coef[(q == 0 ? 0 : 3 + q) * g.Cin + c];
+            cin[e] = v;
+        }
+    } else {
+        for (int e = tid; e < 4 * g.Cin; e += TH_THREADS) {
+            float v = (e >= 2 * g.Cin && e < 3 * g.Cin) ? 1.f : 0.f;
+            if (a.in.mode == TR_BN) v = a.in.coef[e];
+            cin[e] = v;
+        }
+        if (tid == 0) cin[4 * g.Cin] = (a.in.mode == TR_BN && a.in.relu) ? 0.f : -__builtin_inff();
+    }
+    if (EPBN) {
+        for (int e = tid; e < 4 * g.N; e += TH_THREADS) cep[e] = a.ep_coef[e];
+        if (tid == 0) cep[4 * g.N] = a.ep_relu ? 0.f : -__builtin_inff();
+    }
+    int sch[MIDC_NE], sdst[MIDC_NE];
+#pragma unroll
+    for (int j = 0; j < MIDC_NE; ++j) {
+        const int e = min(tid + 256 * j, CHW - 1);
+        const int c = (int)fdiv((uint32_t)e, g.d_HW), pos = e - c * HW;
+        const int ih = (int)fdiv((uint32_t)pos, g.d_W), iw = pos - ih * g.W;
+        sch[j] = c;
+        sdst[j] = c * HpWp + (ih + g.halo_h) * g.Wp + iw + g.halo_w;
+    }
+    float wreg[MIDC_KS];
+    int koff[MIDC_KS];
+#pragma unroll
+    for (int s = 0; s < MIDC_KS; ++s) {
+        const int k = min(4 * s + lk, K - 1);  // (cls[0] of a plain gather: ntaps = KH * KW, nkw = KW)
+        const int ci = (int)fdiv((uint32_t)k, a.cls[0].d_ntaps), tap = k - ci * KK;
+        const int kh = (int)fdiv((uint32_t)tap, a.cls[0].d_nkw), kw = tap - kh * g.KW;
+        koff[s] = ci * HpWp + kh * g.Wp + kw;
+        const float wv = a.w[ci * g.w_cstride + min(li, g.N - 1) * g.w_nstride + tap];
+        wreg[s] = (4 * s + lk < K && li < g.N) ? wv : 0.f;
+    }
+    const int oh = (int)fdiv((uint32_t)(p_ok ? p_out : 0), a.cls[0].d_AW), ow = (p_ok ? p_out : 0) - oh * g.OW;
+    const int base = oh * g.si_h * g.Wp + ow * g.si_w;
+    float br[4], m_[4], rs_[4], sc_[4], be_[4], s1[4], s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = min(lk * 4 + r, g.N - 1);
+        br[r] = (!EPBN && a.bias != nullptr) ? a.bias[ch] : 0.f;
+        s1[r] = s2[r] = 0.f;
+        m_[r] = rs_[r] = sc_[r] = be_[r] = 0.f;
+    }
+    lds_barrier();
+    if (EPBN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = min(lk * 4 + r, g.N - 1);
+            m_[r] = cep[ch]; rs_[r] = cep[g.N + ch]; sc_[r] = cep[2 * g.N + ch]; be_[r] = cep[3 * g.N + ch];
+        }
+    }
+    const float thr_in = GRADIN ? 0.f : cin[4 * g.Cin];
+    const float thr_ep = EPBN ? cep[4 * g.N] : 0.f;
+    float cnt = 0.f;
+
+    auto store = [&](float* t, const float (&v)[MIDC_NE], const float (&y)[GRADIN ? MIDC_NE : 1]) {
+        float o[MIDC_NE];
+#pragma unroll
+        for (int j = 0; j < MIDC_NE; ++j) {
+            const int c = sch[j];
+            if (GRADIN)
+                o[j] = fmaf(cin[g.Cin + c], v[j], fmaf(cin[2 * g.Cin + c], y[j] - cin[c], cin[3 * g.Cin + c])) * th_act_grad<ACT>(y[j], a.in.slope);
+            else
+                o[j] = fmaxf(fmaf(v[j] - cin[c], cin[2 * g.Cin + c], cin[3 * g.Cin + c]), thr_in);
+        }
+#pragma unroll
+        for (int j = 0; j < MIDC_NE; ++j)
+            if (tid + 256 * j < CHW) t[sdst[j]] = o[j];
+    };
+    auto compute = [&](const float* t, int s, const float (&e)[EPBN ? 4 : 1]) {
+        if (s > last) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* p = t + base;
+#pragma unroll
+        for (int q = 0; q < MIDC_KS; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[q], p[koff[q]], acc, 0, 0, 0);
+        float* o = a.out + (int64_t)s * g.N * OHW + (p_ok ? p_out : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = p_ok && lk * 4 + r < g.N;
+            if (EPBN) {
+                const float xc = e[r] - m_[r];
+                float d = fmaf(xc, sc_[r], be_[r]) > thr_ep ? acc[r] : 0.f;
+                d = ok ? d : 0.f;
+                s1[r] += d;
+                s2[r] = fmaf(d, xc * rs_[r], s2[r]);
+                if (ok) o[(lk * 4 + r) * OHW] = d;
+            } else {
+                // (GRADIN: ACT is the activation of the layer whose gradient comes in; the result has none)
+                const float v = GRADIN ? acc[r] + br[r] : th_act<ACT>(acc[r] + br[r], a.slope);
+                if (ok) o[(lk * 4 + r) * OHW] = v;
+                const float d = ok ? v - br[r] : 0.f;  // statistics pivot: the channel's bias
+                s1[r] += d;
+                s2[r] = fmaf(d, d, s2[r]);
+            }
+        }
+        cnt += (float)OHW;
+    };
+
+    store(img[0], vA, yA);
+    float eC[EPBN ? 4 : 1];  // (the epilogue values of the sample being computed survive the reload of their set)
+#pragma unroll
+    for (int r = 0; r < (EPBN ? 4 : 1); ++r) eC[r] = eA[r];
+    load(blockIdx.x + 2 * G, vA, yA, eA);
+    for (int s = blockIdx.x; s <= last; s += 2 * G) {
+        lds_barrier();  // image 0 is complete, image 1 is free
+        compute(img[0], s, eC);
+        store(img[1], vB, yB);
+#pragma unroll
+        for (int r = 0; r < (EPBN ? 4 : 1); ++r) eC[r] = eB[r];
+        load(s + 3 * G, vB, yB, eB);
+        lds_barrier();
+        compute(img[1], s + G, eC);
+        store(img[0], vA, yA);
+#pragma unroll
+        for (int r = 0; r < (EPBN ? 4 : 1); ++r) eC[r] = eA[r];
+        load(s + 4 * G, vA, yA, eA);
+    }
+
+    if (a.slab == nullptr) return;  // (uniform)
+    // ---- per-channel sums: over the 16 pixel lanes of a channel row (DPP), then over the four waves
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s1[r] = dpp_add<0x111, 0xf>(s1[r]); s1[r] = dpp_add<0x112, 0xf>(s1[r]);
+        s1[r] = dpp_add<0x114, 0xf>(s1[r]); s1[r] = dpp_add<0x118, 0xf>(s1[r]);
+        s2[r] = dpp_add<0x111, 0xf>(s2[r]); s2[r] = dpp_add<0x112, 0xf>(s2[r]);
+        s2[r] = dpp_add<0x114, 0xf>(s2[r]); s2[r] = dpp_add<0x118, 0xf>(s2[r]);
+        if (li == 15) {  // lane 15 of a row holds the row's sum
+            red[(wid * 16 + lk * 4 + r) * 2] = s1[r];
+            red[(wid * 16 + lk * 4 + r) * 2 + 1] = s2[r];
+        }
+    }
+    if (lane == 0) red[128 + wid] = cnt;
+    __syncthreads();
+    if (tid < g.N) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            t1 += red[(w * 16 + tid) * 2];
+            t2 += red[(w * 16 + tid) * 2 + 1];
+        }
+        float* sl = a.slab + ((int64_t)blockIdx.x * g.N + tid) * 4;
+        if (EPBN) {
+            sl[0] = t1; sl[1] = t2; sl[2] = 0.f; sl[3] = 0.f;
+        } else {
+            sl[0] = a.bias != nullptr ? a.bias[tid] : 0.f;
+            sl[1] = t1; sl[2] = t2; sl[3] = red[128];  // every wave counted the workgroup's samples
+        }
+    }
+}

@@ -803,6 +803,35 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     }
     a.d_N = mk_fdiv(a.g.N);
     a.d_ntile = mk_fdiv(a.g.Np / 16);
+    {   // mid-size plain gathers stream whole samples instead (thin.h: mid_conv_k)
+        static const int mid_on = [] { const char* e = getenv("VAE_AMD_MID"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
+        const IgGeom& q = a.g;
+        const bool gradin = a.in.mode >= TR_GRAD_BN;
+        const int actv = gradin ? a.in.act : a.act;
+        if (mid_on && !g_bf16 && !q.transposed && q.so_h == 1 && q.so_w == 1 && q.N <= 16 && q.Cin * q.KH * q.KW <= 4 * MIDC_KS &&
+            q.OH * q.OW <= 64 && q.Cin * q.H * q.W <= 256 * MIDC_NE && (!gradin || a.act == VAE_ACT_NONE) &&
+            (a.ep_mode == EP_PLAIN || gradin)) {
+            int grid = mid_grid(c.B);
+            if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
+            const size_t mbytes = (size_t)(2 * q.Cin * q.Hp * q.Wp + 4 * q.Cin + 4 + 4 * q.N + 4 + 136) * sizeof(float);
+            const bool epbn = a.ep_mode == EP_BNGRAD;
+#define MIDC_LAUNCH(GI, EP, AC) hipLaunchKernelGGL((mid_conv_k<GI, EP, AC>), dim3(grid), dim3(TH_THREADS), mbytes, c.s, a)
+#define MIDC_ACT(GI, EP)                                                   \
+    do {                                                                   \
+        if (actv == VAE_ACT_SIGMOID) MIDC_LAUNCH(GI, EP, VAE_ACT_SIGMOID); \
+        else if (actv == VAE_ACT_LEAKY) MIDC_LAUNCH(GI, EP, VAE_ACT_LEAKY); \
+        else MIDC_LAUNCH(GI, EP, VAE_ACT_NONE);                            \
+    } while (0)
+            if (!gradin) MIDC_ACT(false, false);
+            else if (epbn) MIDC_ACT(true, true);
+            else MIDC_ACT(true, false);
+#undef MIDC_ACT
+#undef MIDC_LAUNCH
+            VAE_LAUNCH_CHECK("mid_conv_k");
+            if (a.slab != nullptr) c.last_blocks = grid;
+            return VAE_OK;
+        }
+    }
     const int g_max = IG_MAX_GRID;
     const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
