@@ -492,53 +492,56 @@ struct MidWgArgs {
     TensorIn S, G;
     float* part;      // [grid][MT*NT*256 + 64]
     int want_bias;
-    int B;
+    int B, SBR;       // SBR samples per round: SBR * SH * SW <= 64 pixels (the MFMA's K of a round)
     int Sc, SH, SW;   // S: channels, small grid
     int Gc, GH, GW;   // G: channels, big grid
     int KH, KW, sh, sw, ph, pw;
     int Hp, Wp;       // padded G image (halo = ph, pw on the low side)
     float slope;
-    FastDiv dS_HW, dS_W, dG_HW, dG_W, d_KK, d_KW;
+    FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW;
 };
-#define MID_NS 4   // S elements per thread: Sc*SH*SW <= 1024
-#define MID_NG 7   // G elements per thread: Gc*GH*GW <= 1792
-#define MID_KSW 4  // k-steps per wave: SH*SW <= 64
+#define MID_KSW 4  // k-steps per wave: SBR * SH * SW <= 64
 
-template <int MT, int NT, bool S_GRAD, int ACT>
+// NS / NG: staged elements per thread and round of S / G (SBR * Sc * SH * SW <= 256 * NS, likewise G).
+template <int MT, int NT, int NS, int NG, bool S_GRAD, int ACT>
 __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int SHW = a.SH * a.SW, GHW = a.GH * a.GW, HpWp = a.Hp * a.Wp, KK = a.KH * a.KW, NK = a.Gc * KK;
-    const int nS = a.Sc * SHW, nG = a.Gc * GHW, imgG = a.Gc * HpWp;
+    const int nS1 = a.Sc * SHW, nG1 = a.Gc * GHW, imgG1 = a.Gc * HpWp;  // per sample
+    const int nS = a.SBR * nS1, nG = a.SBR * nG1, imgG = a.SBR * imgG1;  // per round
     const TensorIn& tin = S_GRAD ? a.G : a.S;   // the input-type tensor
     const TensorIn& tgr = S_GRAD ? a.S : a.G;   // the gradient-type tensor
     const int Cin_t = S_GRAD ? a.Gc : a.Sc, Cgr_t = S_GRAD ? a.Sc : a.Gc;
-    // LDS: [2][nS] S tiles, [2][imgG] G images, input coefs [4*Cin_t + 4], gradient coefs [4*Cgr_t], bias scratch / reduce
+    // LDS: [2][nS] S tiles, [2][imgG] G images, input coefs [4*Cin_t + 4], gradient coefs [4*Cgr_t]; reduce area at the end
     float* lS[2] = {smem, smem + nS};
     float* lG[2] = {smem + 2 * nS, smem + 2 * nS + imgG};
     float* cin = smem + 2 * nS + 2 * imgG;
     float* cgr = cin + 4 * Cin_t + 4;
-    const int g = gridDim.x, last = a.B - 1;
+    const int g = gridDim.x;
+    const int nrounds = (a.B + a.SBR - 1) / a.SBR, last = nrounds - 1;
 
-    // staged elements of this thread: S slot j -> element tid + 256 j (channel fixed per slot), same for G
-    float sA[MID_NS], sB[MID_NS], sAy[S_GRAD ? MID_NS : 1], sBy[S_GRAD ? MID_NS : 1];
-    float gA[MID_NG], gB[MID_NG], gAy[S_GRAD ? 1 : MID_NG], gBy[S_GRAD ? 1 : MID_NG];
-    auto load = [&](int s, float (&sv)[MID_NS], float (&sy)[S_GRAD ? MID_NS : 1], float (&gv)[MID_NG],
-                    float (&gy)[S_GRAD ? 1 : MID_NG]) {
-        s = min(s, last);
-        const float* ps = a.S.src + (int64_t)s * nS;
-        const float* pg = a.G.src + (int64_t)s * nG;
+    float sA[NS], sB[NS], sAy[S_GRAD ? NS : 1], sBy[S_GRAD ? NS : 1];
+    float gA[NG], gB[NG], gAy[S_GRAD ? 1 : NG], gBy[S_GRAD ? 1 : NG];
+    auto load = [&](int rd, float (&sv)[NS], float (&sy)[S_GRAD ? NS : 1], float (&gv)[NG], float (&gy)[S_GRAD ? 1 : NG]) {
+        rd = min(rd, last);
+        const int t0 = (int)opaque_tid();  // (keeps the slots' 64-bit addresses from being hoisted out of the round loop)
+        const int sbr = min(a.SBR, a.B - rd * a.SBR);
+        const float* ps = a.S.src + (int64_t)rd * nS;
+        const float* pg = a.G.src + (int64_t)rd * nG;
+        const float* ps2 = S_GRAD ? a.S.src2 + (int64_t)rd * nS : nullptr;
+        const float* pg2 = S_GRAD ? nullptr : a.G.src2 + (int64_t)rd * nG;
 #pragma unroll
-        for (int j = 0; j < MID_NS; ++j) {
-            const int e = min(tid + 256 * j, nS - 1);
+        for (int j = 0; j < NS; ++j) {
+            const int e = min(t0 + 256 * j, sbr * nS1 - 1);
             sv[j] = ps[e];
-            if (S_GRAD) sy[j] = a.S.src2[(int64_t)s * nS + e];
+            if (S_GRAD) sy[j] = ps2[e];
         }
 #pragma unroll
-        for (int j = 0; j < MID_NG; ++j) {
-            const int e = min(tid + 256 * j, nG - 1);
+        for (int j = 0; j < NG; ++j) {
+            const int e = min(t0 + 256 * j, sbr * nG1 - 1);
             gv[j] = pg[e];
-            if (!S_GRAD) gy[j] = a.G.src2[(int64_t)s * nG + e];
+            if (!S_GRAD) gy[j] = pg2[e];
         }
     };
     load(blockIdx.x, sA, sAy, gA, gAy);
@@ -558,29 +561,36 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
         if (tgr.mode == TR_GRAD_BN) v = tgr.coef[(q == 0 ? 0 : 3 + q) * Cgr_t + c];
         cgr[e] = v;
     }
-    // per-slot constants: channel and LDS destination
-    int sch[MID_NS], gch[MID_NG], gdst[MID_NG];
+    // per-slot constants: channel and LDS destination (a round's S and G are contiguous in global memory:
+    // [sample][channel][pixel], and S keeps that layout in LDS)
+    int sch[NS], gch[NG], gdst[NG];
 #pragma unroll
-    for (int j = 0; j < MID_NS; ++j) sch[j] = (int)fdiv((uint32_t)min(tid + 256 * j, nS - 1), a.dS_HW);
+    for (int j = 0; j < NS; ++j) {
+        const int e = min(tid + 256 * j, nS - 1);
+        const int sl = (int)fdiv((uint32_t)e, a.dS_CHW);
+        sch[j] = (int)fdiv((uint32_t)(e - sl * nS1), a.dS_HW);
+    }
 #pragma unroll
-    for (int j = 0; j < MID_NG; ++j) {
+    for (int j = 0; j < NG; ++j) {
         const int e = min(tid + 256 * j, nG - 1);
-        const int c = (int)fdiv((uint32_t)e, a.dG_HW), pos = e - c * GHW;
+        const int sl = (int)fdiv((uint32_t)e, a.dG_CHW), r = e - sl * nG1;
+        const int c = (int)fdiv((uint32_t)r, a.dG_HW), pos = r - c * GHW;
         const int ih = (int)fdiv((uint32_t)pos, a.dG_W), iw = pos - ih * a.GW;
         gch[j] = c;
-        gdst[j] = c * HpWp + (ih + a.ph) * a.Wp + iw + a.pw;
+        gdst[j] = sl * imgG1 + c * HpWp + (ih + a.ph) * a.Wp + iw + a.pw;
     }
     // MFMA index sets: this wave's k-steps are wid, wid + 4, ...; pixel of a step for this lane: 4 * step + lk
-    int pS[MID_KSW], pG[MID_KSW];
-    float pOn[MID_KSW];
+    int pS[MID_KSW], pG[MID_KSW], pP[MID_KSW];
 #pragma unroll
     for (int q = 0; q < MID_KSW; ++q) {
-        const int p = 4 * (wid + 4 * q) + lk;
-        const bool on = p < SHW;
-        const int oh = (int)fdiv((uint32_t)(on ? p : 0), a.dS_W), ow = (on ? p : 0) - oh * a.SW;
-        pS[q] = on ? p : 0;
-        pG[q] = oh * a.sh * a.Wp + ow * a.sw;
-        pOn[q] = on ? 1.f : 0.f;
+        const int p = 4 * (wid + 4 * q) + lk;  // pixel of the round: (sample, oh, ow)
+        const int sl = (int)fdiv((uint32_t)p, a.dS_HW);
+        const bool on = sl < a.SBR;
+        const int pix = on ? p - sl * SHW : 0, sl0 = on ? sl : 0;
+        const int oh = (int)fdiv((uint32_t)pix, a.dS_W), ow = pix - oh * a.SW;
+        pS[q] = sl0 * nS1 + pix;
+        pG[q] = sl0 * imgG1 + oh * a.sh * a.Wp + ow * a.sw;
+        pP[q] = on ? p : 0x7fffffff;
     }
     int moff[MT], koffN[NT];
 #pragma unroll
@@ -595,20 +605,20 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int NB = S_GRAD ? MID_NS : MID_NG;  // bias partials: one per gradient slot (its channel is fixed)
+    constexpr int NB = S_GRAD ? NS : NG;  // bias partials: one per gradient slot (its channel is fixed)
     float bacc[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) bacc[j] = 0.f;
     lds_barrier();
     const float thr = cin[4 * Cin_t];
 
-    // transform + store one sample's registers into buffer b; the gradient values also feed the bias partials
-    auto store = [&](int b, int s, const float (&sv)[MID_NS], const float (&sy)[S_GRAD ? MID_NS : 1], const float (&gv)[MID_NG],
-                     const float (&gy)[S_GRAD ? 1 : MID_NG]) {
-        const float live = s <= last ? 1.f : 0.f;
-        float so[MID_NS], go[MID_NG];
+    // transform + store one round's registers into buffer b; the gradient values also feed the bias partials
+    auto store = [&](int b, int rd, const float (&sv)[NS], const float (&sy)[S_GRAD ? NS : 1], const float (&gv)[NG],
+                     const float (&gy)[S_GRAD ? 1 : NG]) {
+        const int sbr = rd <= last ? min(a.SBR, a.B - rd * a.SBR) : 0;  // (0: nothing of this round counts)
+        float so[NS], go[NG];
 #pragma unroll
-        for (int j = 0; j < MID_NS; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int c = sch[j];
             if (S_GRAD) {
                 const float y = sy[j];
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < MID_NG; ++j) {
+        for (int j = 0; j < NG; ++j) {
             const int c = gch[j];
             if (!S_GRAD) {
                 const float y = gy[j];
@@ -628,28 +638,28 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < MID_NS; ++j) {
-            const bool in = tid + 256 * j < nS;
-            if (in) lS[b][tid + 256 * j] = so[j];
-            if (S_GRAD) bacc[j] += in ? so[j] * live : 0.f;
+        for (int j = 0; j < NS; ++j) {
+            if (tid + 256 * j < nS) lS[b][tid + 256 * j] = so[j];
+            if (S_GRAD) bacc[j] += tid + 256 * j < sbr * nS1 ? so[j] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < MID_NG; ++j) {
-            const bool in = tid + 256 * j < nG;
-            if (in) lG[b][gdst[j]] = go[j];
-            if (!S_GRAD) bacc[j] += in ? go[j] * live : 0.f;
+        for (int j = 0; j < NG; ++j) {
+            if (tid + 256 * j < nG) lG[b][gdst[j]] = go[j];
+            if (!S_GRAD) bacc[j] += tid + 256 * j < sbr * nG1 ? go[j] : 0.f;
         }
     };
-    auto compute = [&](int b, int s) {
-        if (s > last) return;
+    auto compute = [&](int b, int rd) {
+        if (rd > last) return;
+        const int P = min(a.SBR, a.B - rd * a.SBR) * SHW;  // pixels of this round
         const float* S = lS[b];
         const float* G = lG[b];
 #pragma unroll
         for (int q = 0; q < MID_KSW; ++q) {
-            if (4 * (wid + 4 * q) >= SHW) break;  // (wave-uniform)
+            if (4 * (wid + 4 * q) >= P) break;  // (wave-uniform)
+            const float on = pP[q] < P ? 1.f : 0.f;
             float av[MT], bv[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = S[moff[mt] + pS[q]] * pOn[q];
+            for (int mt = 0; mt < MT; ++mt) av[mt] = S[moff[mt] + pS[q]] * on;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = G[pG[q] + koffN[nt]];
 #pragma unroll
@@ -661,34 +671,38 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
 
     store(0, blockIdx.x, sA, sAy, gA, gAy);
     load(blockIdx.x + 2 * g, sA, sAy, gA, gAy);
-    for (int s = blockIdx.x; s <= last; s += 2 * g) {
+    for (int rd = blockIdx.x; rd <= last; rd += 2 * g) {
         lds_barrier();  // buffer 0 is complete, buffer 1 is free
-        compute(0, s);
-        store(1, s + g, sB, sBy, gB, gBy);
-        load(s + 3 * g, sB, sBy, gB, gBy);
+        compute(0, rd);
+        store(1, rd + g, sB, sBy, gB, gBy);
+        load(rd + 3 * g, sB, sBy, gB, gBy);
         lds_barrier();
-        compute(1, s + g);
-        store(0, s + 2 * g, sA, sAy, gA, gAy);
-        load(s + 4 * g, sA, sAy, gA, gAy);
+        compute(1, rd + g);
+        store(0, rd + 2 * g, sA, sAy, gA, gAy);
+        load(rd + 4 * g, sA, sAy, gA, gAy);
     }
 
-    // ---- cross-wave reduction (the staging buffers are dead) and the partial row
-    __syncthreads();
-    constexpr int TE = MT * NT * 256;
-    float* red = smem;  // [4][TE] (the host sizes the dynamic LDS for it)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wid * TE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
-    __syncthreads();
+    // ---- cross-wave reduction (the staging buffers are dead), MT*NT tiles in passes of <= 5, and the partial row
+    constexpr int TE = MT * NT * 256, RT = MT * NT < 5 ? MT * NT : 5;
+    float* red = smem;  // [4][RT * 256] (the host sizes the dynamic LDS for it)
     float* row = a.part + (int64_t)blockIdx.x * (TE + 64);
-    for (int i = tid; i < TE; i += TH_THREADS) row[i] = (red[i] + red[TE + i]) + (red[2 * TE + i] + red[3 * TE + i]);
+#pragma unroll
+    for (int t0 = 0; t0 < MT * NT; t0 += RT) {
+        __syncthreads();
+#pragma unroll
+        for (int t = t0; t < t0 + RT && t < MT * NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid * RT * 256 + ((t - t0) * 4 + r) * 64 + lane] = acc[t / NT][t % NT][r];
+        __syncthreads();
+        const int cnt = min(RT, MT * NT - t0) * 256;
+        for (int i = tid; i < cnt; i += TH_THREADS)
+            row[t0 * 256 + i] = (red[i] + red[RT * 256 + i]) + (red[2 * RT * 256 + i] + red[3 * RT * 256 + i]);
+    }
     __syncthreads();
-    // bias gradient: every slot's partial goes to its element's place, then one thread per channel adds the plane
+    // bias gradient: every slot's partial goes to its element's place in the round, then one thread per channel adds
+    // its planes (fixed order)
     if (a.want_bias) {
-        const int nB = S_GRAD ? nS : nG, HWb = S_GRAD ? SHW : GHW, Cb = S_GRAD ? a.Sc : a.Gc;
+        const int nB = S_GRAD ? nS : nG, nB1 = S_GRAD ? nS1 : nG1, HWb = S_GRAD ? SHW : GHW, Cb = S_GRAD ? a.Sc : a.Gc;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             if (tid + 256 * j < nB) red[tid + 256 * j] = bacc[j];
@@ -696,7 +710,8 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
         if (tid < 64) {
             float t = 0.f;
             if (tid < Cb)
-                for (int i = 0; i < HWb; ++i) t += red[tid * HWb + i];
+                for (int sl = 0; sl < a.SBR; ++sl)
+                    for (int i = 0; i < HWb; ++i) t += red[sl * nB1 + tid * HWb + i];
             row[TE + tid] = t;
         }
     } else if (tid < 64) {

@@ -614,15 +614,27 @@ static int mid_grid(int B) {
     }
     return B < cap ? B : cap;
 }
-// S: Sc channels on SH x SW, G: Gc channels on GH x GW (roles as in igemm_wgrad_k)
-static bool mid_wgrad_ok(int Sc, int SH, int SW, int Gc, int GH, int GW, int KH, int KW, int MT, int NT) {
+// S: Sc channels on SH x SW, G: Gc channels on GH x GW (roles as in igemm_wgrad_k).  Returns the samples per round
+// (0: not eligible) and the instance: 1 = <1, 5, NS 4, NG 7> (8 <-> 16 channels), 2 = <2, 10, NS 5, NG 13> (16 <-> 32)
+static int mid_wgrad_sbr(int Sc, int SH, int SW, int Gc, int GH, int GW, int KH, int KW, int MT, int NT, int* inst) {
     static int on = -1;
     if (on < 0) {
         const char* e = getenv("VAE_AMD_MID");
         on = (e != nullptr && *e) ? atoi(e) != 0 : 1;
     }
-    return on && MT == 1 && NT == 5 && Sc <= 16 && SH * SW <= 16 * MID_KSW && Sc * SH * SW <= 256 * MID_NS &&
-           Gc * GH * GW <= 256 * MID_NG && Gc * KH * KW <= 80;
+    *inst = 0;
+    if (!on || Gc > 64 || Sc > 64) return 0;
+    int ns, ng;
+    if (MT == 1 && NT == 5) { *inst = 1; ns = 4; ng = 7; }
+    else if (MT == 2 && NT == 10) { *inst = 2; ns = 5; ng = 13; }
+    else return 0;
+    const int shw = SH * SW, ns1 = Sc * shw, ng1 = Gc * GH * GW;
+    if (shw < 1 || shw > 64) return 0;
+    int sbr = 64 / shw;
+    if (sbr * ns1 > 256 * ns) sbr = 256 * ns / ns1;
+    if (sbr * ng1 > 256 * ng) sbr = 256 * ng / ng1;
+    if (sbr < 1) *inst = 0;
+    return sbr < 1 ? 0 : sbr;
 }
 static int64_t mid_part_floats(int B, int T) { return (int64_t)(B < MID_MAX_GRID ? B : MID_MAX_GRID) * (T * 256 + 64); }
 
@@ -731,8 +743,9 @@ extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
                        : plan_wgrad(B, g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw);
     if (w.SB < 1) return 0;
     int64_t need = wgrad_part_floats(w, B);
-    const bool mid_ok = T ? mid_wgrad_ok(g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, w.MT, w.NT)
-                          : mid_wgrad_ok(g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, w.MT, w.NT);
+    int mid_inst = 0;
+    const bool mid_ok = (T ? mid_wgrad_sbr(g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, w.MT, w.NT, &mid_inst)
+                           : mid_wgrad_sbr(g.Cout, g.OH, g.OW, g.Cin, g.H, g.W, g.KH, g.KW, w.MT, w.NT, &mid_inst)) > 0;
     const int64_t thin = thin_kind(g, T) != 0 ? thin_part_floats(B) : 0, mid = mid_ok ? mid_part_floats(B, w.MT * w.NT) : 0;
     if (thin > need) need = thin;
     return mid > need ? mid : need;
@@ -1008,32 +1021,43 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     wa.d_bC = mk_fdiv(wa.bias_from_S ? wa.Sc : wa.Gc);
     wa.lds_S = wp.lds_S; wa.lds_G = wp.lds_G; wa.lds_tab = wp.lds_tab;
     wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
-    if (!g_bf16 && mid_wgrad_ok(wa.Sc, wa.SH, wa.SW, wa.Gc, wa.GH, wa.GW, g.KH, g.KW, wp.MT, wp.NT) &&
-        (op.act == VAE_ACT_NONE || op.act == VAE_ACT_LEAKY)) {
+    int mid_inst = 0;
+    const int mid_sbr = g_bf16 ? 0 : mid_wgrad_sbr(wa.Sc, wa.SH, wa.SW, wa.Gc, wa.GH, wa.GW, g.KH, g.KW, wp.MT, wp.NT, &mid_inst);
+    if (mid_sbr > 0 && (op.act == VAE_ACT_NONE || op.act == VAE_ACT_LEAKY)) {
         MidWgArgs m;
         memset(&m, 0, sizeof(m));
-        m.S = wa.S; m.G = wa.G; m.want_bias = db != nullptr; m.B = c.B;
+        m.S = wa.S; m.G = wa.G; m.want_bias = db != nullptr; m.B = c.B; m.SBR = mid_sbr;
         m.Sc = wa.Sc; m.SH = wa.SH; m.SW = wa.SW; m.Gc = wa.Gc; m.GH = wa.GH; m.GW = wa.GW;
         m.KH = g.KH; m.KW = g.KW; m.sh = g.sh; m.sw = g.sw; m.ph = g.ph; m.pw = g.pw; m.Hp = wp.Hp; m.Wp = wp.Wp;
         m.slope = op.f[0];
-        m.dS_HW = mk_fdiv(wa.SH * wa.SW); m.dS_W = mk_fdiv(wa.SW);
-        m.dG_HW = mk_fdiv(wa.GH * wa.GW); m.dG_W = mk_fdiv(wa.GW);
+        m.dS_HW = mk_fdiv(wa.SH * wa.SW); m.dS_W = mk_fdiv(wa.SW); m.dS_CHW = mk_fdiv(wa.Sc * wa.SH * wa.SW);
+        m.dG_HW = mk_fdiv(wa.GH * wa.GW); m.dG_W = mk_fdiv(wa.GW); m.dG_CHW = mk_fdiv(wa.Gc * wa.GH * wa.GW);
         m.d_KK = mk_fdiv(g.KH * g.KW); m.d_KW = mk_fdiv(g.KW);
-        const int grid = mid_grid(c.B);
+        int grid = mid_grid((c.B + mid_sbr - 1) / mid_sbr);
+        if (mid_inst == 2 && grid > 256) grid = 256;  // (20 accumulator tiles: one workgroup per CU; 512: 36 us, 256: 25 us)
         const int TE = wp.MT * wp.NT * 256;
         m.part = resolve(c, op.r[10], (int64_t)grid * (TE + 64), "conv.wgrad_partials", &ok);
         if (!ok) return VAE_EINVAL;
-        const int nS = wa.Sc * wa.SH * wa.SW, imgG = wa.Gc * wp.Hp * wp.Wp;
+        const int nS = mid_sbr * wa.Sc * wa.SH * wa.SW, imgG = mid_sbr * wa.Gc * wp.Hp * wp.Wp;
+        const int nGr = mid_sbr * wa.Gc * wa.GH * wa.GW;
         int fl = 2 * nS + 2 * imgG + 4 * (wa.Sc + wa.Gc) + 8;
-        if (fl < 4 * TE) fl = 4 * TE;
+        if (fl < 4 * 5 * 256) fl = 4 * 5 * 256;          // the cross-wave reduction's passes of five tiles
+        if (fl < (nS > nGr ? nS : nGr)) fl = nS > nGr ? nS : nGr;  // the bias partials of a round
         const size_t bytes = (size_t)fl * sizeof(float);
-        if (!T) {  // Conv: S is the gradient
-            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<1, 5, true, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
-            else hipLaunchKernelGGL((mid_wgrad_k<1, 5, true, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
-        } else {
-            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<1, 5, false, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
-            else hipLaunchKernelGGL((mid_wgrad_k<1, 5, false, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m);
-        }
+#define MIDW_LAUNCH(MTv, NTv, NSv, NGv)                                                                                              \
+    do {                                                                                                                           \
+        if (!T) {  /* Conv: S is the gradient */                                                                                   \
+            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<MTv, NTv, NSv, NGv, true, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m); \
+            else hipLaunchKernelGGL((mid_wgrad_k<MTv, NTv, NSv, NGv, true, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m); \
+        } else {                                                                                                                   \
+            if (op.act == VAE_ACT_LEAKY) hipLaunchKernelGGL((mid_wgrad_k<MTv, NTv, NSv, NGv, false, VAE_ACT_LEAKY>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m); \
+            else hipLaunchKernelGGL((mid_wgrad_k<MTv, NTv, NSv, NGv, false, VAE_ACT_NONE>), dim3(grid), dim3(TH_THREADS), bytes, c.s, m); \
+        }                                                                                                                          \
+    } while (0)
+        if (bytes > 64 * 1024) VAE_FAIL(VAE_EINVAL, "mid wgrad: %zu bytes of LDS", bytes);
+        if (mid_inst == 1) MIDW_LAUNCH(1, 5, 4, 7);
+        else MIDW_LAUNCH(2, 10, 5, 13);
+#undef MIDW_LAUNCH
         VAE_LAUNCH_CHECK("mid_wgrad_k");
         if (c.wg_fin.n == WG_FIN_MAX_LAYERS && (rc = flush_wgrad_finalize(c)) != VAE_OK) return rc;
         WgFinLayer& L = c.wg_fin.l[c.wg_fin.n++];
