@@ -172,7 +172,9 @@ int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world);
  * the Python program builder; no GPU needed). */
 int vae_conv_fused_ok(const vae_op* op, int B);
 /* Which instance of the fused forward kernel the op gets at batch B (host-only; bench.py groups its launches
- * by kernel name with it): 0 = not fused, else 100*NT + ND as in igemm_gather_k<NT, 2, false, ND>. */
+ * by kernel name with it): 0 = not fused, 300 = the streaming kernels of the single-channel outer layers (thin_conv_fwd_k /
+ * thin_convT_fwd_k), 400 = the streaming kernel of mid-size plain convolutions (mid_conv_k), else 100*NT + ND as in
+ * igemm_gather_k<NT, 2, false, ND>. */
 int vae_conv_forward_variant(const vae_op* op, int B);
 /* Floats of shared scratch (the op's r[6] slot) a FUSED CONV/CONVT op needs at batch B for its BatchNorm statistic
  * slabs (+ the gathered data-parallel rows).  0 if not fusable. */

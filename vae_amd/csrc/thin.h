@@ -735,6 +735,8 @@ template <bool GRADIN, bool EPBN, int ACT>
 __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
+    IG_TDECL;
+    IG_T();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int HW = g.H * g.W, CHW = g.Cin * HW, HpWp = g.Hp * g.Wp, OHW = g.OH * g.OW, KK = g.KH * g.KW, K = g.Cin * KK;
     const int imgN = g.Cin * HpWp;
@@ -769,6 +771,7 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
     };
     load(blockIdx.x, vA, yA, eA);
     load(blockIdx.x + G, vB, yB, eB);
+    IG_T();
 
     // ---- once per workgroup
     for (int e = tid; e < 2 * imgN; e += TH_THREADS) smem[e] = 0.f;  // the halo stays zero
@@ -791,6 +794,7 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
         for (int e = tid; e < 4 * g.N; e += TH_THREADS) cep[e] = a.ep_coef[e];
         if (tid == 0) cep[4 * g.N] = a.ep_relu ? 0.f : -__builtin_inff();
     }
+    IG_T();
     int sch[MIDC_NE], sdst[MIDC_NE];
 #pragma unroll
     for (int j = 0; j < MIDC_NE; ++j) {
@@ -800,17 +804,22 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
         sch[j] = c;
         sdst[j] = c * HpWp + (ih + g.halo_h) * g.Wp + iw + g.halo_w;
     }
+    IG_T();
     float wreg[MIDC_KS];
     int koff[MIDC_KS];
+    // (all 18 weight loads are issued before any of them is used: with the mask applied in the same loop the
+    // compiler waited for every load in turn, 18 x 270 ns of a 6 us set-up)
 #pragma unroll
     for (int s = 0; s < MIDC_KS; ++s) {
         const int k = min(4 * s + lk, K - 1);  // (cls[0] of a plain gather: ntaps = KH * KW, nkw = KW)
         const int ci = (int)fdiv((uint32_t)k, a.cls[0].d_ntaps), tap = k - ci * KK;
         const int kh = (int)fdiv((uint32_t)tap, a.cls[0].d_nkw), kw = tap - kh * g.KW;
         koff[s] = ci * HpWp + kh * g.Wp + kw;
-        const float wv = a.w[ci * g.w_cstride + min(li, g.N - 1) * g.w_nstride + tap];
-        wreg[s] = (4 * s + lk < K && li < g.N) ? wv : 0.f;
+        wreg[s] = a.w[ci * g.w_cstride + min(li, g.N - 1) * g.w_nstride + tap];
     }
+#pragma unroll
+    for (int s = 0; s < MIDC_KS; ++s) wreg[s] = (4 * s + lk < K && li < g.N) ? wreg[s] : 0.f;
+    IG_T();
     const int oh = (int)fdiv((uint32_t)(p_ok ? p_out : 0), a.cls[0].d_AW), ow = (p_ok ? p_out : 0) - oh * g.OW;
     const int base = oh * g.si_h * g.Wp + ow * g.si_w;
     float br[4], m_[4], rs_[4], sc_[4], be_[4], s1[4], s2[4];
@@ -876,6 +885,7 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
         cnt += (float)OHW;
     };
 
+    IG_T();
     store(img[0], vA, yA);
     float eC[EPBN ? 4 : 1];  // (the epilogue values of the sample being computed survive the reload of their set)
 #pragma unroll
@@ -883,19 +893,26 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
     load(blockIdx.x + 2 * G, vA, yA, eA);
     for (int s = blockIdx.x; s <= last; s += 2 * G) {
         lds_barrier();  // image 0 is complete, image 1 is free
+        IG_T();
         compute(img[0], s, eC);
+        IG_T();
         store(img[1], vB, yB);
 #pragma unroll
         for (int r = 0; r < (EPBN ? 4 : 1); ++r) eC[r] = eB[r];
         load(s + 3 * G, vB, yB, eB);
+        IG_T();
         lds_barrier();
+        IG_T();
         compute(img[1], s + G, eC);
+        IG_T();
         store(img[0], vA, yA);
 #pragma unroll
         for (int r = 0; r < (EPBN ? 4 : 1); ++r) eC[r] = eA[r];
         load(s + 4 * G, vA, yA, eA);
     }
 
+    IG_T();
+    IG_TPRINT("mid_conv: setup | [barrier] compute store+load [barrier] compute (store+load) ...");
     if (a.slab == nullptr) return;  // (uniform)
     // ---- per-channel sums: over the 16 pixel lanes of a channel row (DPP), then over the four waves
 #pragma unroll

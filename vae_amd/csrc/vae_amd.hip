@@ -751,6 +751,11 @@ extern "C" int64_t vae_conv_wgrad_partial_floats(const vae_op* op, int B) {
     return mid > need ? mid : need;
 }
 
+// plain gathers that stream whole samples on mid_conv_k (thin.h) instead of the chunked kernel
+static bool mid_conv_geom_ok(const IgGeom& q) {
+    return !g_bf16 && !q.transposed && q.so_h == 1 && q.so_w == 1 && q.N <= 16 && q.Cin * q.KH * q.KW <= 4 * MIDC_KS &&
+           q.OH * q.OW <= 64 && q.Cin * q.H * q.W <= 256 * MIDC_NE;
+}
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
 static int gather_direct_nd(const IgGeom& g, const IgClass* cls, int ncls);
 extern "C" int vae_conv_forward_variant(const vae_op* op, int B) {
@@ -758,6 +763,11 @@ extern "C" int vae_conv_forward_variant(const vae_op* op, int B) {
     const ConvGeom g = geom_of(*op);
     const int T = op->kind == VAE_OP_CONVT;
     const IgGeom f = make_geom(T, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, !T);
+    if (op->r[8] < 0 && thin_kind(g, T) != 0 && (thin_kind(g, T) == 2 || op->r[7] < 0)) return 300;  // thin.h streaming kernels
+    {
+        static const int mid_on = [] { const char* e = getenv("VAE_AMD_MID"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
+        if (mid_on && mid_conv_geom_ok(f)) return 400;  // mid_conv_k
+    }
     IgClass cls[4];
     int wsum, tsum;
     const int ncls = fill_classes(f, cls, &wsum, &tsum);
@@ -821,9 +831,7 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
         const IgGeom& q = a.g;
         const bool gradin = a.in.mode >= TR_GRAD_BN;
         const int actv = gradin ? a.in.act : a.act;
-        if (mid_on && !g_bf16 && !q.transposed && q.so_h == 1 && q.so_w == 1 && q.N <= 16 && q.Cin * q.KH * q.KW <= 4 * MIDC_KS &&
-            q.OH * q.OW <= 64 && q.Cin * q.H * q.W <= 256 * MIDC_NE && (!gradin || a.act == VAE_ACT_NONE) &&
-            (a.ep_mode == EP_PLAIN || gradin)) {
+        if (mid_on && mid_conv_geom_ok(q) && (!gradin || a.act == VAE_ACT_NONE) && (a.ep_mode == EP_PLAIN || gradin)) {
             int grid = mid_grid(c.B);
             if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
             const size_t mbytes = (size_t)(2 * q.Cin * q.Hp * q.Wp + 4 * q.Cin + 4 + 4 * q.N + 4 + 136) * sizeof(float);
