@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "chan.h"
@@ -18,6 +19,7 @@
 #include "lin.h"
 #include "wide.h"
 #include "thin.h"
+#include "fc.h"
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
@@ -56,6 +58,7 @@ struct Ctx {
     int n_bases;
     int B;
     hipStream_t s;
+    int fc;                   // runs of LINEAR / REPARAM ops go through fc_chain_k
     mutable int last_blocks;  // blocks that wrote the per-channel slab consumed by the next BN finalize
     mutable LinWgMulti lin_wg;  // Linear weight gradients deferred to one launch at the end of backward
     mutable WgFinMulti wg_fin;  // conv weight-gradient partial reductions, likewise
@@ -1477,6 +1480,268 @@ static int reparam_backward(const Ctx& c, const vae_op& op) {
     return VAE_OK;
 }
 
+// ---- a run of LINEAR / REPARAM ops as one launch (fc.h) ---------------------------------------
+#define FC_LDS_MAX_FLOATS 16384  // 64 KB of dynamic LDS
+static int fc_enabled() {  // read once per run (make_ctx), so that a test can compare the two paths in one process
+    const char* e = getenv("VAE_AMD_FC");
+    return !(e != nullptr && e[0] == '0') && !g_bf16;
+}
+static inline bool fc_kind(const vae_op& op) { return op.kind == VAE_OP_LINEAR || op.kind == VAE_OP_REPARAM; }
+
+struct FcBuf {
+    int64_t ref;
+    int width, ld, level;
+    int stage, slot;  // producer (index into the unsorted stage list; slot 1: a REPARAM_BWD's second output)
+    bool consumed;
+};
+struct FcBuild {
+    FcChain ch;
+    FcBuf buf[2 * FC_MAX_STAGES];
+    int nbuf;
+    bool overflow;
+    FcBuild() : nbuf(0), overflow(false) { memset(&ch, 0, sizeof(ch)); }
+    int find(int64_t ref, int width, int ld) const {
+        for (int i = 0; i < nbuf; ++i)
+            if (buf[i].ref == ref && buf[i].width == width && buf[i].ld == ld) return i;
+        return -1;
+    }
+    // rows [B][width] at stride ld from `ref` share floats with a buffer of the run (column slices of one buffer, the
+    // same buffer under another shape): such programs stay on the op-by-op path
+    bool overlaps(int64_t ref, int width, int ld, int B) const {
+        const int64_t lo = ref, hi = ref + (int64_t)(B - 1) * ld + width;  // (the space is in the top byte: no carry)
+        for (int i = 0; i < nbuf; ++i) {
+            const int64_t blo = buf[i].ref, bhi = blo + (int64_t)(B - 1) * buf[i].ld + buf[i].width;
+            if (lo < bhi && blo < hi) return true;
+        }
+        return false;
+    }
+    int add_buf(int64_t ref, int width, int ld, int level, int stage, int slot) {
+        if (nbuf == 2 * FC_MAX_STAGES) { overflow = true; return 0; }
+        buf[nbuf] = FcBuf{ref, width, ld, level, stage, slot, false};
+        return nbuf++;
+    }
+    FcStage* add_stage(int kind, int level) {
+        if (ch.n == FC_MAX_STAGES) { overflow = true; return &ch.st[0]; }
+        FcStage* s = &ch.st[ch.n++];
+        memset(s, 0, sizeof(*s));
+        s->kind = kind; s->level = level;
+        s->in_off = s->in2_off = s->out_off = s->out2_off = -1;
+        return s;
+    }
+    // an input of the run: the LDS rows of (ref, width, ld), loaded from global memory when nothing in the run made them
+    int input(const Ctx& c, int64_t ref, int width, int ld, const char* what, bool* ok) {
+        int b = find(ref, width, ld);
+        if (b < 0) {
+            if (overlaps(ref, width, ld, c.B)) { overflow = true; return 0; }
+            FcStage* s = add_stage(FC_LOAD, 0);
+            s->N = width;
+            s->src = resolve(c, ref, (int64_t)(c.B - 1) * ld + width, what, ok);
+            s->ld_src = ld;
+            b = add_buf(ref, width, ld, 0, ch.n - 1, 0);
+        }
+        buf[b].consumed = true;
+        return b;
+    }
+};
+
+// LDS offsets for every buffer that a stage reads, stages sorted by level; 1: ready, 0: not for this path
+static int fc_finish(FcBuild& fb, int B) {
+    if (fb.overflow || fb.ch.n == 0) return 0;
+    FcChain& ch = fb.ch;
+    int off = 0, boff[2 * FC_MAX_STAGES], bstr[2 * FC_MAX_STAGES];
+    for (int i = 0; i < fb.nbuf; ++i) {
+        boff[i] = -1; bstr[i] = 0;
+        if (!fb.buf[i].consumed) continue;
+        bstr[i] = (fb.buf[i].width + 47) / 48 * 48 + 4;  // fc_chain_k reads A three k-steps (48 columns) at a time
+        boff[i] = off;
+        off += FC_ROWS * bstr[i];
+    }
+    if (off > FC_LDS_MAX_FLOATS) return 0;
+    ch.lds_floats = off;
+    for (int i = 0; i < fb.nbuf; ++i) {  // producers' destinations
+        FcStage& s = ch.st[fb.buf[i].stage];
+        if (fb.buf[i].slot == 0) { s.out_off = boff[i]; s.out_stride = bstr[i]; }
+        else { s.out2_off = boff[i]; s.out2_stride = bstr[i]; }
+    }
+    for (int k = 0; k < ch.n; ++k) {  // consumers' sources: in_off / in2_off hold buffer indices + 1 until here
+        FcStage& s = ch.st[k];
+        if (s.kind == FC_LOAD) continue;
+        const int b1 = s.in_off, b2 = s.in2_off;
+        s.in_off = boff[b1]; s.in_stride = bstr[b1];
+        if (b2 >= 0) { s.in2_off = boff[b2]; s.in2_stride = bstr[b2]; }
+    }
+    int nlev = 0;
+    for (int k = 0; k < ch.n; ++k) nlev = ch.st[k].level + 1 > nlev ? ch.st[k].level + 1 : nlev;
+    std::stable_sort(ch.st, ch.st + ch.n, [](const FcStage& a, const FcStage& b) { return a.level < b.level; });
+    ch.B = B;
+    for (int k = 0; k < ch.n; ++k) {  // fc_fetch loads the bias and act'(Y) unconditionally: absent ones read a weight
+        FcStage& s = ch.st[k];
+        if (s.kind != FC_GEMM) continue;
+        s.has_bias = s.bias != nullptr; s.has_mul = s.mulY != nullptr;
+        if (!s.has_bias) s.bias = s.W;
+        if (!s.has_mul) s.mulY = s.W;
+    }
+    // every wave's work list: per level its share of the tiles (dealt round-robin), the element-wise stages, a barrier
+    int cnt[FC_WAVES];
+    for (int w = 0; w < FC_WAVES; ++w) cnt[w] = 0;
+    auto push = [&](int w, int kind, int stage, int tile) {
+        if (cnt[w] == FC_MAX_ITEMS) return false;
+        const uint32_t it = (uint32_t)((kind << 12) | (stage << 8) | tile), sh = (cnt[w] & 1) * 16;
+        ch.items[w][cnt[w] >> 1] = (ch.items[w][cnt[w] >> 1] & ~(0xffffu << sh)) | (it << sh);
+        ++cnt[w];
+        return true;
+    };
+    bool fits = true;
+    for (int lev = 0, k = 0; lev < nlev; ++lev) {
+        const int k0 = k;
+        int g = 0;
+        for (; k < ch.n && ch.st[k].level == lev; ++k) {
+            if (ch.st[k].kind != FC_GEMM) continue;
+            const int ntile = (ch.st[k].N + 15) / 16;
+            if (ntile > 256) return 0;
+            for (int t = 0; t < ntile; ++t, ++g) fits = fits && push(g % FC_WAVES, FC_IT_TILE, k, t);
+        }
+        for (int q = k0; q < k; ++q)
+            if (ch.st[q].kind != FC_GEMM)
+                for (int w = 0; w < FC_WAVES; ++w) fits = fits && push(w, FC_IT_ELEM, q, 0);
+        for (int w = 0; w < FC_WAVES; ++w) fits = fits && push(w, FC_IT_BARRIER, 0, 0);
+    }
+    if (!fits) return 0;
+    for (int w = 0; w < FC_WAVES; ++w) ch.n_items[w] = (uint32_t)cnt[w];
+    return 1;
+}
+static int fc_launch(const Ctx& c, const FcChain& ch, const char* what) {
+    bool vec = false;  // some GEMM stage takes dwordx4 weight loads
+    for (int k = 0; k < ch.n; ++k) vec = vec || (ch.st[k].kind == FC_GEMM && ch.st[k].vec);
+    const dim3 grid((c.B + FC_ROWS - 1) / FC_ROWS);
+    const size_t bytes = (size_t)ch.lds_floats * sizeof(float);
+    if (vec) hipLaunchKernelGGL(fc_chain_k<true>, grid, dim3(FC_THREADS), bytes, c.s, ch);
+    else hipLaunchKernelGGL(fc_chain_k<false>, grid, dim3(FC_THREADS), bytes, c.s, ch);
+    VAE_LAUNCH_CHECK(what);
+    return VAE_OK;
+}
+
+// forward of ops[0..n) (all LINEAR / REPARAM).  1: launched, 0: not for this path (run the ops one by one), < 0: error
+static int fc_forward(const Ctx& c, const vae_op* ops, int n) {
+    FcBuild fb;
+    bool ok = true;
+    for (int j = 0; j < n && !fb.overflow; ++j) {
+        const vae_op& op = ops[j];
+        if (op.kind == VAE_OP_LINEAR) {
+            if (linear_check(c, op) != VAE_OK) return VAE_EINVAL;
+            const int K = op.d[0], N = op.d[1], ldx = op.d[2], ldy = op.d[3];
+            const int bi = fb.input(c, op.r[0], K, ldx, "linear.in", &ok);
+            if (fb.overlaps(op.r[1], N, ldy, c.B)) return 0;
+            FcStage* s = fb.add_stage(FC_GEMM, fb.buf[bi].level + 1);
+            s->in_off = bi;
+            s->K = K; s->N = N;
+            s->W = resolve(c, op.r[4], (int64_t)N * K, "linear.w", &ok);
+            s->wsk = 1; s->wsn = K;
+            s->vec = (K % 4 == 0 && ((uintptr_t)s->W & 15) == 0) ? 1 : 0;
+            s->bias = resolve_opt(c, op.r[5], N, "linear.b", &ok);
+            s->act = op.act; s->slope = op.f[0];
+            s->out = resolve(c, op.r[1], strided_extent(c.B, ldy, N), "linear.out", &ok);
+            s->ldo = ldy;
+            fb.add_buf(op.r[1], N, ldy, s->level, fb.ch.n - 1, 0);
+        } else {
+            const int L = op.d[0];
+            if (L < 1) VAE_FAIL(VAE_EINVAL, "reparam: bad latent");
+            const int bm = fb.input(c, op.r[0], L, L, "reparam.mu", &ok);
+            const int bl = fb.input(c, op.r[1], L, L, "reparam.logvar", &ok);
+            if (fb.overlaps(op.r[3], L, L, c.B)) return 0;
+            const int lev = (fb.buf[bm].level > fb.buf[bl].level ? fb.buf[bm].level : fb.buf[bl].level) + 1;
+            FcStage* s = fb.add_stage(FC_REPARAM_FWD, lev);
+            s->in_off = bm; s->in2_off = bl;
+            s->N = L;
+            s->src = resolve(c, op.r[2], (int64_t)c.B * L, "reparam.eps", &ok);
+            s->ld_src = L;
+            s->out = resolve(c, op.r[3], (int64_t)c.B * L, "reparam.z", &ok);
+            s->ldo = L;
+            fb.add_buf(op.r[3], L, L, lev, fb.ch.n - 1, 0);
+        }
+        if (!ok) return VAE_EINVAL;
+    }
+    if (!fc_finish(fb, c.B)) return 0;
+    return fc_launch(c, fb.ch, "fc_chain_k(fwd)") == VAE_OK ? 1 : VAE_EHIP;
+}
+
+// input gradients of ops[0..n) (walked backwards); the weight gradients are registered by the caller afterwards
+static int fc_backward(const Ctx& c, const vae_op* ops, int n) {
+    FcBuild fb;
+    bool ok = true;
+    // the LDS rows of an op's dout, times act'(Y) of that op
+    auto dout_rows = [&](const vae_op& op) -> int {
+        const int N = op.d[1], ldy = op.d[3], lddy = op.d[5];
+        const int before = fb.nbuf;
+        const int b = fb.input(c, op.r[3], N, lddy, "linear.dout", &ok);
+        if (fb.overflow) return 0;
+        FcStage& p = fb.ch.st[fb.buf[b].stage];
+        if (b < before && (p.mulY != nullptr || fb.buf[b].slot != 0 || p.kind == FC_REPARAM_BWD) && op.act != VAE_ACT_NONE) {
+            fb.overflow = true;  // a second consumer, or a producer without the multiplier
+            return 0;
+        }
+        if (op.act != VAE_ACT_NONE) {
+            p.mulY = resolve(c, op.r[1], strided_extent(c.B, ldy, N), "linear.out", &ok);
+            p.ldmy = ldy; p.mul_act = op.act; p.mul_slope = op.f[0];
+        }
+        return b;
+    };
+    for (int j = n - 1; j >= 0 && !fb.overflow; --j) {
+        const vae_op& op = ops[j];
+        if (op.kind == VAE_OP_LINEAR) {
+            if (linear_check(c, op) != VAE_OK) return VAE_EINVAL;
+            const int K = op.d[0], N = op.d[1], lddx = op.d[4], lddy = op.d[5];
+            if (lddy < N || (op.r[2] >= 0 && lddx < K)) VAE_FAIL(VAE_EINVAL, "linear: bad grad leading dims");
+            if (op.r[2] < 0) continue;  // no input gradient wanted
+            const vae_op* sib = (j - 1 >= 0 && linear_dgrad_siblings(ops[j - 1], op)) ? &ops[j - 1] : nullptr;
+            const int b1 = dout_rows(op);
+            const int b2 = sib != nullptr ? dout_rows(*sib) : -1;
+            if (fb.overflow) break;
+            if (fb.overlaps(op.r[2], K, lddx, c.B)) return 0;  // a second writer of one gradient buffer inside the run
+            int lev = fb.buf[b1].level;
+            if (b2 >= 0 && fb.buf[b2].level > lev) lev = fb.buf[b2].level;
+            FcStage* s = fb.add_stage(FC_GEMM, lev + 1);
+            s->in_off = b1; s->in2_off = b2;
+            s->K = N; s->N = K;
+            s->W = resolve(c, op.r[4], (int64_t)N * K, "linear.w", &ok);
+            if (sib != nullptr) s->W2 = resolve(c, sib->r[4], (int64_t)N * K, "linear.w", &ok);
+            s->wsk = K; s->wsn = 1;
+            s->out = resolve(c, op.r[2], strided_extent(c.B, lddx, K), "linear.din", &ok);
+            s->ldo = lddx;
+            s->accumulate = (op.flags & VAE_F_ACC_DIN) ? 1 : 0;  // (of a pair: the later op's, which writes first)
+            fb.add_buf(op.r[2], K, lddx, s->level, fb.ch.n - 1, 0);
+            if (sib != nullptr) --j;
+        } else {
+            const int L = op.d[0];
+            const int64_t cnt = (int64_t)c.B * L;
+            const int bz = fb.input(c, op.r[4], L, L, "reparam.dz", &ok);
+            if (fb.overflow) break;
+            if (fb.overlaps(op.r[5], L, L, c.B) || fb.overlaps(op.r[6], L, L, c.B)) return 0;
+            FcStage* s = fb.add_stage(FC_REPARAM_BWD, fb.buf[bz].level + 1);
+            s->in_off = bz;
+            s->N = L;
+            s->mu = resolve(c, op.r[0], cnt, "reparam.mu", &ok);
+            s->lv = resolve(c, op.r[1], cnt, "reparam.logvar", &ok);
+            s->src = resolve(c, op.r[2], cnt, "reparam.eps", &ok);
+            s->ld_src = L;
+            s->out = resolve(c, op.r[5], cnt, "reparam.dmu", &ok);
+            s->out2 = resolve(c, op.r[6], cnt, "reparam.dlogvar", &ok);
+            s->ldo = L;
+            if (op.flags & VAE_F_EXT_GRAD) {
+                s->g_mu = resolve(c, op.r[7], cnt, "reparam.g_mu", &ok);
+                s->g_lv = resolve(c, op.r[8], cnt, "reparam.g_logvar", &ok);
+            }
+            if (op.flags & VAE_F_KL_GRAD) s->gscale = resolve_opt(c, op.r[9], 1, "reparam.gscale", &ok);
+            s->kl_grad = (op.flags & VAE_F_KL_GRAD) ? 1 : 0;
+            fb.add_buf(op.r[5], L, L, s->level, fb.ch.n - 1, 0);
+            fb.add_buf(op.r[6], L, L, s->level, fb.ch.n - 1, 1);
+        }
+        if (!ok) return VAE_EINVAL;
+    }
+    if (!fc_finish(fb, c.B)) return 0;
+    return fc_launch(c, fb.ch, "fc_chain_k(bwd)") == VAE_OK ? 1 : VAE_EHIP;
+}
+
 static int slice0_forward(const Ctx& c, const vae_op& op) {
     const int C = op.d[0], L = op.d[1];
     if (C < 1 || L < 1) VAE_FAIL(VAE_EINVAL, "slice0: bad shape");
@@ -1553,6 +1818,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     if (n_bases < 4 || n_bases > 128) VAE_FAIL(VAE_EINVAL, "n_bases=%d out of range", n_bases);
     if (B < 1 || B > (1 << 24)) VAE_FAIL(VAE_EINVAL, "batch %d out of range", B);
     c->bases = bases; c->sizes = sizes; c->n_bases = n_bases; c->B = B; c->s = (hipStream_t)stream;
+    c->fc = fc_enabled();
     c->last_blocks = 0;
     c->lin_wg.n = 0;
     c->wg_fin.n = 0;
@@ -1582,6 +1848,13 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
         if (sq_use(ops, n_ops, B, &sq)) return sq_forward(c, ops, &sq, training);
     }
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
+        if (c.fc && fc_kind(ops[i])) {  // a run of Linear / reparam ops: one launch (fc.h)
+            int n = 1;
+            while (i + n < n_ops && fc_kind(ops[i + n])) ++n;
+            const int r = n >= 2 ? fc_forward(c, ops + i, n) : 0;
+            if (r < 0) return r;
+            if (r == 1) { i += n - 1; continue; }
+        }
         if (i + 1 < n_ops && linear_siblings(ops[i], ops[i + 1])) {
             rc = linear_forward(c, ops[i], &ops[i + 1]);
             ++i;
@@ -1681,6 +1954,18 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
         if (zero_in_elbo && i == op_end - 1) {
             rc = elbo_backward(c, op, bases[2], base_sizes[2]);
             continue;
+        }
+        if (c.fc && fc_kind(op)) {  // a run of Linear / reparam ops: the input gradients in one launch (fc.h)
+            int j = i;
+            while (j - 1 >= op_begin && fc_kind(ops[j - 1])) --j;
+            const int r = i - j + 1 >= 2 ? fc_backward(c, ops + j, i - j + 1) : 0;
+            if (r < 0) return r;
+            if (r == 1) {  // (after the launch: a full weight-gradient list flushes at once and reads what it wrote)
+                for (int k = i; k >= j && rc == VAE_OK; --k)
+                    if (ops[k].kind == VAE_OP_LINEAR) rc = linear_backward(c, ops[k], nullptr, true);
+                i = j;
+                continue;
+            }
         }
         switch (op.kind) {
             case VAE_OP_CONV:
