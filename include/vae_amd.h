@@ -66,6 +66,9 @@ enum {
     VAE_F_FUSED = 64,      /* CONV/CONVT: LDS-staged MFMA implicit-GEMM kernels; BN: "virtual" (its output is
                               never materialised: the producer's epilogue takes the statistics, the consumer
                               normalises on load, and the backward pass is folded the same way) */
+    VAE_F_LOSS_IN_BWD = 128, /* ELBO: forward leaves the per-workgroup partials; the fixed-order sum into out[0..3]
+                              is done by the op's backward launch (a train step always runs it: one launch less).
+                              No counterpart in the reference (train.py:39-48 computes the loss eagerly). */
 };
 
 /* One program op.  Field use per kind ("-" unused):

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("VAE_AMD_LIB") or os.path.join(_HERE, "csrc", "libvae_
 OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
+F_LOSS_IN_BWD = 128
 MAX_CHUNKS, ELBO_BLOCKS, MAX_WORLD = 64, 1024, 64
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
 

@@ -124,7 +124,28 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
                                                   const float* __restrict__ gscale, float* __restrict__ dxr,
                                                   float* __restrict__ dmu, float* __restrict__ dlv, int64_t B,
                                                   int nps, int64_t t_sb, int64_t t_se, int latent, int bce,
-                                                  float* __restrict__ zero_buf, int64_t zero_n) {
+                                                  float* __restrict__ zero_buf, int64_t zero_n,
+                                                  const float* __restrict__ fin_partials = nullptr,
+                                                  float* __restrict__ fin_out = nullptr, int fin_blocks = 0,
+                                                  int fin_accumulate = 0) {
+    // fin_partials: the forward left the fixed-order sum of its partials to this launch (VAE_F_LOSS_IN_BWD: one graph
+    // node less per train step); workgroup 0 does what elbo_finalize_k does
+    if (fin_partials != nullptr && blockIdx.x == 0) {
+        __shared__ float sm[4];
+        float r = 0.f, k = 0.f;
+        for (int i = threadIdx.x; i < fin_blocks; i += blockDim.x) {
+            r += fin_partials[2 * i];
+            k += fin_partials[2 * i + 1];
+        }
+        r = block_sum_256(r, sm);
+        k = block_sum_256(k, sm);
+        if (threadIdx.x == 0) {
+            fin_out[0] = r + k;
+            fin_out[1] = r;
+            fin_out[2] = k;
+            if (fin_accumulate) fin_out[3] += r + k;
+        }
+    }
     const float gs = gscale != nullptr ? gscale[0] : 1.f;
     const int64_t nrec = B * nps, nkl = B * latent;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

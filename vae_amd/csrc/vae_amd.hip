@@ -1768,10 +1768,11 @@ static int slice0_backward(const Ctx& c, const vae_op& op) {
 
 static int elbo_fwd_impl(hipStream_t s, const float* xr, const float* tg, const float* mu, const float* lv, float* out,
                          float* partials, int B, int nps, int64_t t_sb, int64_t t_se, int latent, int bce,
-                         int accumulate) {
+                         int accumulate, bool finalize = true) {
     hipLaunchKernelGGL(elbo_fwd_k, dim3(VAE_ELBO_BLOCKS), dim3(256), 0, s, xr, tg, mu, lv, partials, (int64_t)B, nps,
                        t_sb, t_se, latent, bce);
     VAE_LAUNCH_CHECK("elbo_fwd_k");
+    if (!finalize) return VAE_OK;  // VAE_F_LOSS_IN_BWD: summed by the op's backward launch
     hipLaunchKernelGGL(elbo_finalize_k, dim3(1), dim3(256), 0, s, partials, out, VAE_ELBO_BLOCKS, accumulate);
     VAE_LAUNCH_CHECK("elbo_finalize_k");
     return VAE_OK;
@@ -1791,7 +1792,7 @@ static int elbo_forward(const Ctx& c, const vae_op& op) {
     float* part = resolve(c, op.r[6], 2 * VAE_ELBO_BLOCKS, "elbo.partials", &ok);
     if (!ok) return VAE_EINVAL;
     return elbo_fwd_impl(c.s, xr, tg, mu, lv, out, part, c.B, nps, op.d[1], op.d[2], latent,
-                         (op.flags & VAE_F_BCE) ? 1 : 0, op.d[5]);
+                         (op.flags & VAE_F_BCE) ? 1 : 0, op.d[5], !(op.flags & VAE_F_LOSS_IN_BWD));
 }
 static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullptr, int64_t zero_n = 0) {
     const int nps = op.d[0], latent = op.d[3];
@@ -1800,11 +1801,17 @@ static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullp
     const float* tg = resolve(c, op.r[1], target_extent(c.B, nps, op.d[1], op.d[2]), "elbo.target", &ok);
     float* dxr = resolve(c, op.r[5], (int64_t)c.B * nps, "elbo.dx_rec", &ok);
     const float* gs = resolve_opt(c, op.r[7], 1, "elbo.gscale", &ok);
+    const float* fin_part = nullptr;
+    float* fin_out = nullptr;
+    if (op.flags & VAE_F_LOSS_IN_BWD) {  // the forward left the sum of its partials to this launch
+        fin_part = resolve(c, op.r[6], 2 * VAE_ELBO_BLOCKS, "elbo.partials", &ok);
+        fin_out = resolve(c, op.r[4], 4, "elbo.out", &ok);
+    }
     if (!ok) return VAE_EINVAL;
     // KL gradients are folded into the REPARAM op's backward (VAE_F_KL_GRAD)
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid((int64_t)c.B * nps)), dim3(256), 0, c.s, xr, tg, nullptr, nullptr, gs,
                        dxr, nullptr, nullptr, (int64_t)c.B, nps, (int64_t)op.d[1], (int64_t)op.d[2], latent,
-                       (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n);
+                       (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n, fin_part, fin_out, VAE_ELBO_BLOCKS, op.d[5]);
     VAE_LAUNCH_CHECK("elbo_bwd_k");
     return VAE_OK;
 }

@@ -161,9 +161,11 @@ class ProgramBuilder:
         self._op(L.OP_SLICE0, r=(x.ref, y.ref, x.gref, y.gref), d=(C, Lw))
         return y
 
-    def elbo(self, x_rec, target_ref, t_sb, t_se, mu, logvar, latent, bce, accumulate=True):
+    def elbo(self, x_rec, target_ref, t_sb, t_se, mu, logvar, latent, bce, accumulate=True, loss_in_bwd=False):
+        """loss_in_bwd: the sum of the partials into out[0..3] is left to the op's backward launch (train steps, which
+        always run it); a forward-only run of such a program leaves `out` stale."""
         out = self.fixed(4)
-        op = self._op(L.OP_ELBO, flags=L.F_BCE if bce else 0,
+        op = self._op(L.OP_ELBO, flags=(L.F_BCE if bce else 0) | (L.F_LOSS_IN_BWD if loss_in_bwd else 0),
                       r=(x_rec.ref, target_ref, mu.ref, logvar.ref, out, x_rec.gref, -1, -1),
                       d=(x_rec.n, t_sb, t_se, latent, 0, 1 if accumulate else 0))
         self._need_scratch(op, 6, 2 * L.ELBO_BLOCKS)

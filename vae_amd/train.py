@@ -157,7 +157,7 @@ class FusedTrainStep:
         z = b.reparam(mu, logvar, eps, model.latent_total, kl_grad=True)
         x_rec = model.emit_decoder(b, z)
         t_sb, t_se = model.target_strides()
-        self.out_ref = b.elbo(x_rec, x.ref, t_sb, t_se, mu, logvar, model.latent_total, self.bce)
+        self.out_ref = b.elbo(x_rec, x.ref, t_sb, t_se, mu, logvar, model.latent_total, self.bce, loss_in_bwd=True)
         self.prog = b.build()
         self.bufs = dict(x_rec=(x_rec, model.out_shape), mu=(mu, (model.latent_total,)),
                          logvar=(logvar, (model.latent_total,)))
