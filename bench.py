@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-ref", action="store_true", help="skip the N=1 measurement at global batch 65536")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="N > 1 on RCCL: capture the data-parallel step (collectives included) into one hipGraph")
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="compute dtype of the matrix kernels: f32 (the headline) or bf16 operands with fp32 accumulate "
@@ -324,7 +326,7 @@ def main():
         stepper = FusedTrainStep(model, opt, B, dev, use_graph=not args.no_graph)
     else:
         from vae_amd.parallel import DataParallelTrainStep
-        stepper = DataParallelTrainStep(model, opt, B, dev)
+        stepper = DataParallelTrainStep(model, opt, B, dev, use_graph=args.dp_graph and backend == "nccl")
     stepper.step(x)
 
     def barrier():
@@ -375,7 +377,9 @@ def main():
         if world == 1:
             par = "single GPU, whole step as one hipGraph" if not args.no_graph else "single GPU, eager launches"
         else:
-            coll = "RCCL" if backend == "nccl" else f"{backend} (rehearsal: ranks share {ngpu} GPU(s), collectives staged through the host)"
+            coll = (("RCCL enqueued by the library on the step's streams, no host callback" +
+                     (", whole step captured as one hipGraph" if stepper.use_graph else ", eager launches"))
+                    if backend == "nccl" else f"{backend} (rehearsal: ranks share {ngpu} GPU(s), collectives staged through the host)")
             par = f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM ({coll})"
         line = {
             "metric": "train samples/sec (whole node)", "value": value, "unit": "samples/s", "n_gpus": world,

@@ -171,6 +171,33 @@ int vae_get_compute_dtype(void);
 typedef int (*vae_allgather_fn)(void* user, float* buf, int64_t floats_per_rank, vae_stream_t stream);
 int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world);
 
+/* The same two exchanges done by the library itself over RCCL, enqueued on the caller's stream: no callback into the
+ * host language between the kernels of a step, so a data-parallel step is one stream-ordered sequence (capturable).
+ * No counterpart in the reference (single device).  librccl is opened at run time from `rccl_path`
+ * (NULL/"": the loader's search path), so a single-GPU user never loads it.
+ *   vae_dp_unique_id       : rank 0 makes the VAE_DP_ID_BYTES id that every rank passes to vae_dp_init (two
+ *                            ncclUniqueIds: one communicator for the SyncBN all-gathers on the compute stream, one for
+ *                            the gradient all-reduces that run beside them on the caller's communication stream);
+ *                            the caller ships it to the other ranks (any side channel: torch.distributed, MPI, a file).
+ *   vae_dp_init            : this rank joins both communicators on the CURRENT device (ncclCommInitRank: collective,
+ *                            every rank calls it).  One pair per process.
+ *   vae_dp_enable(1)       : installs the library's own all-gather as the SyncBN hook (as vae_set_collective would)
+ *                            with the communicator's rank / world; vae_dp_enable(0) removes it.
+ *   vae_dp_all_gather_rows : the hook's exchange on its own: buf = `world` rows of floats_per_rank floats, row `rank`
+ *                            filled; in-place ncclAllGather on `stream`.
+ *   vae_dp_all_reduce_sum  : in-place ncclAllReduce(SUM) of n floats on `stream` (the flat gradient buffer or a
+ *                            bucket of it; the ELBO is a sum over samples, so gradients add).
+ *   vae_dp_world           : world size of the communicator, 0 when there is none.
+ *   vae_dp_shutdown        : destroys the communicator (and removes the hook if it is the installed one). */
+#define VAE_DP_ID_BYTES 256
+int vae_dp_unique_id(const char* rccl_path, void* id256);
+int vae_dp_init(const char* rccl_path, const void* id256, int rank, int world);
+int vae_dp_world(void);
+int vae_dp_enable(int on);
+int vae_dp_all_gather_rows(float* buf, int64_t floats_per_rank, vae_stream_t stream);
+int vae_dp_all_reduce_sum(float* buf, int64_t n, vae_stream_t stream);
+int vae_dp_shutdown(void);
+
 /* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
  * the Python program builder; no GPU needed). */
 int vae_conv_fused_ok(const vae_op* op, int B);

@@ -81,3 +81,56 @@ def test_collective_rccl_single_rank():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_native_rccl_step_single_rank():
+    """The library's own RCCL path (vae_dp_*: SyncBN all-gather + gradient all-reduce enqueued from C on the caller's
+    streams) at world 1, the most one GPU allows (RCCL refuses two ranks on one device): the exchanges run through
+    the C-ABI, the data-parallel step makes no callback into Python, equals the single-GPU fused step bit for bit
+    (an all-reduce over one rank is the identity), and can be captured into one hipGraph, collectives included."""
+    code = (
+        "import os, sys, copy, ctypes, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "import vae_amd\n"
+        "from vae_amd import _lib as L\n"
+        "from vae_amd.parallel import DataParallelTrainStep, native_init\n"
+        "from vae_amd.train import FusedTrainStep\n"
+        "assert native_init() == 1 and L.lib().vae_dp_world() == 1\n"
+        "work = torch.arange(64, dtype=torch.float32, device='cuda')\n"
+        "L.check(L.lib().vae_dp_all_gather_rows(L.ptr(work[16:48]), 32, L.stream_ptr()), 'gather')\n"
+        "g = torch.ones(1000, device='cuda')\n"
+        "L.check(L.lib().vae_dp_all_reduce_sum(L.ptr(g), 1000, L.stream_ptr()), 'reduce')\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(work.cpu(), torch.arange(64.)) and float(g.sum()) == 1000.0\n"
+        "B = 64\n"
+        "torch.manual_seed(5)\n"
+        "ref_m = vae_amd.mnist_vae.VariationalAutoencoder(15).cuda().train()\n"
+        "xs = [torch.rand(B, 1, 28, 28, device='cuda') for _ in range(3)]\n"
+        "es = [torch.randn(B, 15, device='cuda') for _ in range(3)]\n"
+        "def run(make):\n"
+        "    m = copy.deepcopy(ref_m)\n"
+        "    st = make(m, vae_amd.optim.Adam(m.parameters(), lr=1e-3))\n"
+        "    st.inject_eps = True\n"
+        "    losses = []\n"
+        "    for x, e in zip(xs, es):\n"
+        "        st.eps.copy_(e)\n"
+        "        losses.append(float(st.step(x).item()))\n"
+        "    torch.cuda.synchronize()\n"
+        "    return st, losses, st.flat.clone()\n"
+        "_, l0, p0 = run(lambda m, o: FusedTrainStep(m, o, B, 'cuda', use_graph=False, allow_seq1d=False))\n"
+        "for graph in (False, True):\n"
+        "    st, l1, p1 = run(lambda m, o: DataParallelTrainStep(m, o, B, 'cuda', use_graph=graph))\n"
+        "    assert st.native and st.hook_calls == 0\n"
+        "    assert (st.graph is not None) == graph\n"
+        "    assert l1 == l0, (graph, l0, l1)\n"
+        "    assert torch.equal(p0, p1), (graph, float((p0 - p1).abs().max()))\n"
+        "L.check(L.lib().vae_dp_shutdown(), 'shutdown')\n"
+        "assert L.lib().vae_dp_world() == 0\n"
+        "dist.destroy_process_group()\n"
+        "print('NATIVE-OK')\n")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "NATIVE-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

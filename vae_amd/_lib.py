@@ -16,6 +16,7 @@ OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
 F_LOSS_IN_BWD = 128
+DP_ID_BYTES = 256  # include/vae_amd.h: VAE_DP_ID_BYTES
 MAX_CHUNKS, ELBO_BLOCKS, MAX_WORLD = 64, 1024, 64
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4
 
@@ -58,6 +59,13 @@ def lib():
                                          i32, i32, i32]
     L.vae_set_collective.argtypes = [ALLGATHER_FN, vp, i32, i32]
     L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
+    L.vae_dp_unique_id.argtypes = [ctypes.c_char_p, vp]
+    L.vae_dp_init.argtypes = [ctypes.c_char_p, vp, i32, i32]
+    L.vae_dp_world.argtypes = []
+    L.vae_dp_enable.argtypes = [i32]
+    L.vae_dp_all_gather_rows.argtypes = [vp, i64, vp]
+    L.vae_dp_all_reduce_sum.argtypes = [vp, i64, vp]
+    L.vae_dp_shutdown.argtypes = []
     L.vae_conv_forward_variant.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.restype = i64
@@ -82,7 +90,8 @@ def lib():
     L.vae_graph_destroy.argtypes = [vp]
     for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
-                 "vae_graph_launch", "vae_graph_destroy"):
+                 "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
+                 "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -93,7 +102,8 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 
 EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
-           "vae_graph_launch", "vae_graph_destroy")
+           "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
+           "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown")
 
 
 _DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}

@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <mutex>
 
@@ -716,6 +718,130 @@ extern "C" int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int
     }
     if (world > VAE_MAX_WORLD || rank < 0 || rank >= world) VAE_FAIL(VAE_EINVAL, "set_collective: bad rank %d / world %d", rank, world);
     g_allgather = fn; g_allgather_user = user; g_rank = rank; g_world = world;
+    return VAE_OK;
+}
+
+// ---- data parallel: RCCL called from here -------------------------------------------------------
+// The SyncBN all-gather and the gradient all-reduce enqueued on the caller's HIP stream by the library itself (no
+// callback into the host language between the kernels of a step, `stream` honoured, so the step is one stream-ordered
+// sequence that a hipGraph can capture).  librccl is opened at run time (the library has no link-time dependency on
+// it; a single-GPU user never loads it); only the six entry points below are used, declared here with RCCL's ABI
+// (rccl.h: ncclUniqueId is 128 opaque bytes passed by value, ncclFloat32 = 7, ncclSum = 0).
+struct DpNcclId { char internal[128]; };
+typedef int (*dp_get_unique_id_fn)(DpNcclId*);
+typedef int (*dp_comm_init_rank_fn)(void**, int, DpNcclId, int);
+typedef int (*dp_comm_destroy_fn)(void*);
+typedef int (*dp_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*dp_all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*dp_error_string_fn)(int);
+static struct {
+    void* handle;
+    dp_get_unique_id_fn get_unique_id;
+    dp_comm_init_rank_fn comm_init_rank;
+    dp_comm_destroy_fn comm_destroy;
+    dp_all_gather_fn all_gather;
+    dp_all_reduce_fn all_reduce;
+    dp_error_string_fn error_string;
+    void* comm;       // SyncBN all-gathers (on the compute stream)
+    void* comm_grad;  // gradient all-reduces (on the caller's communication stream, concurrent with the former)
+    int rank, world;
+} g_dp = {};
+static std::mutex g_dp_mu;
+
+static int dp_load(const char* path) {
+    if (g_dp.handle != nullptr) return VAE_OK;
+    void* h = nullptr;
+    if (path != nullptr && path[0] != 0) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) VAE_FAIL(VAE_EINVAL, "data parallel: cannot open librccl (%s)", dlerror());
+    g_dp.get_unique_id = (dp_get_unique_id_fn)dlsym(h, "ncclGetUniqueId");
+    g_dp.comm_init_rank = (dp_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
+    g_dp.comm_destroy = (dp_comm_destroy_fn)dlsym(h, "ncclCommDestroy");
+    g_dp.all_gather = (dp_all_gather_fn)dlsym(h, "ncclAllGather");
+    g_dp.all_reduce = (dp_all_reduce_fn)dlsym(h, "ncclAllReduce");
+    g_dp.error_string = (dp_error_string_fn)dlsym(h, "ncclGetErrorString");
+    if (!g_dp.get_unique_id || !g_dp.comm_init_rank || !g_dp.comm_destroy || !g_dp.all_gather || !g_dp.all_reduce ||
+        !g_dp.error_string) {
+        dlclose(h);
+        VAE_FAIL(VAE_EINVAL, "data parallel: librccl lacks an entry point");
+    }
+    g_dp.handle = h;
+    return VAE_OK;
+}
+#define VAE_RCCL(expr)                                                                              \
+    do {                                                                                            \
+        const int r_ = (expr);                                                                      \
+        if (r_ != 0) VAE_FAIL(VAE_EHIP, "%s failed: %s", #expr, g_dp.error_string(r_));             \
+    } while (0)
+
+extern "C" int vae_dp_unique_id(const char* rccl_path, void* id256) {
+    void* const id128 = id256;
+    if (id128 == nullptr) VAE_FAIL(VAE_EINVAL, "dp_unique_id: null argument");
+    std::lock_guard<std::mutex> lock(g_dp_mu);
+    int rc = dp_load(rccl_path);
+    if (rc) return rc;
+    DpNcclId id[2];  // one per communicator
+    VAE_RCCL(g_dp.get_unique_id(&id[0]));
+    VAE_RCCL(g_dp.get_unique_id(&id[1]));
+    memcpy(id128, id, sizeof(id));
+    return VAE_OK;
+}
+
+// the hook that vae_dp_enable installs: in-place all-gather of `world` rows (row `rank` is filled)
+static int dp_allgather_hook(void*, float* buf, int64_t n, vae_stream_t stream) {
+    if (g_dp.comm == nullptr) { vae_set_error("data parallel: no communicator"); return 1; }
+    const int r = g_dp.all_gather(buf + (int64_t)g_dp.rank * n, buf, (size_t)n, 7, g_dp.comm, (hipStream_t)stream);
+    if (r != 0) { vae_set_error("ncclAllGather failed: %s", g_dp.error_string(r)); return 1; }
+    return 0;
+}
+
+extern "C" int vae_dp_init(const char* rccl_path, const void* id256, int rank, int world) {
+    const void* const id128 = id256;
+    if (id128 == nullptr || world < 1 || world > VAE_MAX_WORLD || rank < 0 || rank >= world)
+        VAE_FAIL(VAE_EINVAL, "dp_init: bad rank %d / world %d", rank, world);
+    std::lock_guard<std::mutex> lock(g_dp_mu);
+    int rc = dp_load(rccl_path);
+    if (rc) return rc;
+    if (g_dp.comm != nullptr) VAE_FAIL(VAE_EINVAL, "dp_init: a communicator exists already (vae_dp_shutdown first)");
+    DpNcclId id[2];
+    memcpy(id, id128, sizeof(id));
+    void *comm = nullptr, *comm_grad = nullptr;
+    VAE_RCCL(g_dp.comm_init_rank(&comm, world, id[0], rank));  // on the current device; every rank calls it
+    VAE_RCCL(g_dp.comm_init_rank(&comm_grad, world, id[1], rank));
+    g_dp.comm = comm; g_dp.comm_grad = comm_grad; g_dp.rank = rank; g_dp.world = world;
+    return VAE_OK;
+}
+
+extern "C" int vae_dp_world(void) { return g_dp.comm != nullptr ? g_dp.world : 0; }
+
+extern "C" int vae_dp_enable(int on) {
+    if (!on) return vae_set_collective(nullptr, nullptr, 0, 1);
+    if (g_dp.comm == nullptr) VAE_FAIL(VAE_EINVAL, "dp_enable: no communicator (vae_dp_init first)");
+    return vae_set_collective(dp_allgather_hook, nullptr, g_dp.rank, g_dp.world);
+}
+
+extern "C" int vae_dp_all_gather_rows(float* buf, int64_t floats_per_rank, vae_stream_t stream) {
+    if (buf == nullptr || floats_per_rank < 1) VAE_FAIL(VAE_EINVAL, "dp_all_gather_rows: bad arguments");
+    return dp_allgather_hook(nullptr, buf, floats_per_rank, stream) == 0 ? VAE_OK : VAE_EHIP;
+}
+
+extern "C" int vae_dp_all_reduce_sum(float* buf, int64_t n, vae_stream_t stream) {
+    if (buf == nullptr || n < 1) VAE_FAIL(VAE_EINVAL, "dp_all_reduce_sum: bad arguments");
+    if (g_dp.comm == nullptr) VAE_FAIL(VAE_EINVAL, "dp_all_reduce_sum: no communicator (vae_dp_init first)");
+    VAE_RCCL(g_dp.all_reduce(buf, buf, (size_t)n, 7, 0, g_dp.comm_grad, (hipStream_t)stream));
+    return VAE_OK;
+}
+
+extern "C" int vae_dp_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_dp_mu);
+    if (g_allgather == dp_allgather_hook) (void)vae_set_collective(nullptr, nullptr, 0, 1);
+    if (g_dp.comm != nullptr) {
+        void *comm = g_dp.comm, *comm_grad = g_dp.comm_grad;
+        g_dp.comm = g_dp.comm_grad = nullptr; g_dp.world = 0; g_dp.rank = 0;
+        VAE_RCCL(g_dp.comm_destroy(comm));
+        VAE_RCCL(g_dp.comm_destroy(comm_grad));
+    }
     return VAE_OK;
 }
 

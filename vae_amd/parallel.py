@@ -81,20 +81,62 @@ class Collective:
         return t
 
 
+def rccl_path():
+    """The librccl that torch.distributed's nccl backend uses in this process (torch ships its own copy)."""
+    import os
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else ""
+
+
+def native_init(group=None, device=None):
+    """Joins the library's own RCCL communicators (include/vae_amd.h: vae_dp_*) with the ranks of `group`; rank 0's
+    id travels over torch.distributed.  Idempotent per process.  Returns the world size."""
+    lib = L.lib()
+    if lib.vae_dp_world() > 0:
+        return lib.vae_dp_world()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    path = rccl_path().encode()
+    ident = (ctypes.c_ubyte * L.DP_ID_BYTES)()
+    if rank == 0:
+        L.check(lib.vae_dp_unique_id(path, ident), "vae_dp_unique_id")
+    t = torch.tensor(list(ident), dtype=torch.uint8)
+    t = t.to(dev) if dist.get_backend(group) != "gloo" else t
+    dist.broadcast(t, src=0, group=group)
+    ident = (ctypes.c_ubyte * L.DP_ID_BYTES)(*t.cpu().tolist())
+    with torch.cuda.device(dev):
+        L.check(lib.vae_dp_init(path, ident, rank, world), "vae_dp_init")
+    return world
+
+
 class DataParallelTrainStep(FusedTrainStep):
     """FusedTrainStep on this rank's shard with synchronised BatchNorm and a gradient all-reduce.
 
-    `B` is the per-rank batch.  The step is enqueued eagerly on the current stream (collectives are
-    not captured): randn, forward (+ one all-gather of 4*C floats per BatchNorm), ELBO, backward
+    `B` is the per-rank batch.  The step is enqueued on the current stream (native path: optionally captured,
+    collectives included): randn, forward (+ one all-gather of 4*C floats per BatchNorm), ELBO, backward
     (+ one all-gather per BatchNorm), all-reduce SUM of the flat gradient buffer, Adam.  The gradient goes in two
     buckets: backward runs the decoder's ops first (vae_run_backward_range), the all-reduce of the decoder's
     slice of the flat buffer starts on RCCL's stream, and the encoder's backward runs meanwhile; the encoder's
     bucket follows.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
 
-    def __init__(self, model, optimizer, B, device, bce=None, group=None):
+    def __init__(self, model, optimizer, B, device, bce=None, group=None, native=None, use_graph=False):
+        """native: the exchanges are enqueued by the library itself over RCCL (vae_dp_*: no Python between the kernels
+        of a step; default on the nccl backend); otherwise through torch.distributed from the SyncBN callback (gloo:
+        CPU tests, ranks sharing one GPU).  use_graph (native only): the whole step, collectives included, is captured
+        into one hipGraph and replayed."""
         # (the whole-model 1-D path has no synchronised BatchNorm yet: data parallel keeps the per-layer program)
         super().__init__(model, optimizer, B, device, bce=bce, use_graph=False, allow_seq1d=False)
         self.coll = Collective(group)
+        self.native = (self.coll.backend == "nccl" and self.device.type == "cuda") if native is None else bool(native)
+        self.hook_calls = 0  # SyncBN callbacks into Python (0 on the native path)
+        if self.native:
+            native_init(group, self.device)
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            self.use_graph = bool(use_graph)
+        elif use_graph:
+            raise ValueError("use_graph needs the native RCCL path")
         if self.coll.world > L.MAX_WORLD:
             raise ValueError(f"world size {self.coll.world} > {L.MAX_WORLD}")
         # parameters must start identical: rank 0's copy wins (state too)
@@ -118,6 +160,7 @@ class DataParallelTrainStep(FusedTrainStep):
             dist.broadcast(t, src=0, group=self.coll.group)
 
     def _allgather_hook(self, _user, buf, n, _stream):
+        self.hook_calls += 1
         try:
             off = (buf - self.work.data_ptr()) // 4
             if off < 0 or off + self.coll.world * n > self.work.numel():
@@ -128,7 +171,41 @@ class DataParallelTrainStep(FusedTrainStep):
             self._hook_error = e
             return 1
 
+    def _enqueue_native(self, stream):
+        """Everything is enqueued from here in stream order: kernels and SyncBN all-gathers on `stream`, the gradient
+        buckets' all-reduces on the communication stream between two events each, Adam behind the last of them."""
+        lib = L.lib()
+        raw = stream.value if isinstance(stream, ctypes.c_void_p) else stream
+        cs = torch.cuda.ExternalStream(raw, device=self.device) if raw else torch.cuda.current_stream(self.device)
+        if not self.inject_eps:
+            L.check(lib.vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
+        ext = [self.x.view(self.B, -1), self.eps]
+        L.check(lib.vae_dp_enable(1), "vae_dp_enable")
+        try:
+            self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
+            buckets = self.buckets if self.buckets is not None else [(0, self.prog.n_ops, 0, None)]
+            done = []
+            for i, (begin, end, lo, hi) in enumerate(buckets):
+                self.prog.backward_range(self.work, self.flat, self.grads, self.sflat, ext, begin, end, i == 0,
+                                         stream=stream)
+                g = self.grads[lo:hi]
+                ready = torch.cuda.Event()
+                ready.record(cs)
+                self.comm_stream.wait_event(ready)
+                L.check(lib.vae_dp_all_reduce_sum(L.ptr(g), g.numel(), ctypes.c_void_p(self.comm_stream.cuda_stream)),
+                        "vae_dp_all_reduce_sum")
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+                done.append(ev)
+            for ev in done:
+                cs.wait_event(ev)
+        finally:
+            lib.vae_dp_enable(0)
+        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream, hyper=self.hyper)
+
     def _enqueue(self, stream):
+        if self.native:
+            return self._enqueue_native(stream)
         lib = L.lib()
         if not self.inject_eps:
             L.check(lib.vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
