@@ -58,6 +58,8 @@ def lib():
     L.vae_run_backward_range.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
                                          i32, i32, i32]
     L.vae_set_collective.argtypes = [ALLGATHER_FN, vp, i32, i32]
+    L.vae_run_backward_step.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
+                                        vp, vp, vp, vp]
     L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_dp_unique_id.argtypes = [ctypes.c_char_p, vp]
     L.vae_dp_init.argtypes = [ctypes.c_char_p, vp, i32, i32]
@@ -91,7 +93,7 @@ def lib():
     for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
-                 "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown"):
+                 "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -103,7 +105,7 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
-           "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown")
+           "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step")
 
 
 _DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}

@@ -177,6 +177,17 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
 // replays with the right bias correction and the step counter needs no kernel of its own.
 // hyper (optional, device): {lr, beta1, beta2, eps} read at run time instead of the by-value arguments, so a captured
 // graph follows the optimiser's current learning rate (an LR scheduler between replays) without a re-capture.
+// beta^t for the integer step count by repeated squaring in double: <= 31 rounds of two multiplications, where the
+// general pow(double, double) is a few microseconds of code in front of every workgroup's loads (it was most of this
+// kernel's 8 us on 100 k parameters); the product is within ~1e-15 of pow's, far below the float it is rounded to.
+__device__ __forceinline__ double adam_ipow(double b, int t) {
+    double r = 1.0;
+    for (int e = t; e > 0; e >>= 1) {
+        if (e & 1) r *= b;
+        b *= b;
+    }
+    return r;
+}
 __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float beta1, float beta2, float eps, int32_t* tick,
@@ -185,21 +196,28 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const 
     if (hyper != nullptr) {
         lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3];
     }
-    if (threadIdx.x == 0) {
-        const int t = tick[0] + 1;
-        sbc[0] = (float)(1.0 - pow((double)beta1, (double)t));
-        sbc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    const int t = tick[0] + 1;
+    // the first element's operands are requested before the bias corrections are worked out and shared (one latency
+    // round for everything; most threads have exactly one element)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float gi = 0.f, m0 = 0.f, v0 = 0.f, p0 = 0.f;
+    if (i < n) { gi = g[i]; m0 = m[i]; v0 = v[i]; p0 = p[i]; }
+    if (threadIdx.x == 255) {
+        sbc[0] = (float)(1.0 - adam_ipow((double)beta1, t));
+        sbc[1] = (float)(1.0 - adam_ipow((double)beta2, t));
     }
     __syncthreads();
     const float step = lr / sbc[0];
     const float rs2 = rsqrtf(sbc[1]);  // torch: denom = sqrt(v)/sqrt(bc2) + eps
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
-        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+    while (i < n) {
+        const float mi = fmaf(beta1, m0, (1.f - beta1) * gi);
+        const float vi = fmaf(beta2, v0, (1.f - beta2) * gi * gi);
         m[i] = mi;
         v[i] = vi;
-        p[i] -= step * mi / (sqrtf(vi) * rs2 + eps);
+        p[i] = p0 - step * mi / (sqrtf(vi) * rs2 + eps);
+        i += stride;
+        if (i < n) { gi = g[i]; m0 = m[i]; v0 = v[i]; p0 = p[i]; }
     }
     if (threadIdx.x == 0) {
         if (atomicAdd(&tick[1], 1) == (int)gridDim.x - 1) {  // every other workgroup has read tick[0] long ago
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const 
             bc[0] = sbc[0];
             bc[1] = sbc[1];
             tick[1] = 0;
-            tick[0] += 1;
+            tick[0] = t;
         }
     }
 }

@@ -90,7 +90,37 @@ struct SqDesc {
     const float* egscale;  // scale of d(loss)/d(x_rec) (device float) or nullptr (= 1)
     float* dxrec_w;        // [B][C] gradient of the loss w.r.t. x_rec, written by the forward
     float* epart;          // [2][grid]... per-workgroup {recon, kld} partial sums: epart[2*wg], epart[2*wg+1]
+    // VAE_F_LOSS_IN_BWD: the first launch of the backward pass sums the partials into eout[0..3] (no launch of its own)
+    float* eout;
+    int efin, eacc;
 };
+
+// what elbo_finalize_k does, by workgroup 0 of the first backward launch (fixed order: thread t takes the partials
+// t, t + 512, ...; then the block sum)
+// sm_fin: the head of the kernel's dynamic LDS (the phase kernels have the whole 160 KiB granted as dynamic LDS, so
+// a static array of its own would not fit), free again behind the closing barrier.
+__device__ __forceinline__ void sq_elbo_fin(const SqDesc& d, float* sm_fin) {
+    if (!d.efin || blockIdx.x != 0) return;
+    float r = 0.f, k = 0.f;
+    for (int i = threadIdx.x; i < d.grid; i += SQ_THREADS) {
+        r += d.epart[2 * i];
+        k += d.epart[2 * i + 1];
+    }
+    r = wave_sum(r);
+    k = wave_sum(k);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm_fin[2 * wid] = r; sm_fin[2 * wid + 1] = k; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r = k = 0.f;
+        for (int w = 0; w < SQ_WAVES; ++w) { r += sm_fin[2 * w]; k += sm_fin[2 * w + 1]; }
+        d.eout[0] = r + k;
+        d.eout[1] = r;
+        d.eout[2] = k;
+        if (d.eacc) d.eout[3] += r + k;
+    }
+    __syncthreads();
+}
 
 // Helpers below are NOT inlined (one copy in the code object, shared by all six phase kernels): a phase executes
 // nearly all of its code once per launch, so its time is bounded by instruction fetch, and inlining every GEMM /
@@ -1106,6 +1136,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bd_k(SqDesc d, int j) {
     float* prow = d.part + (int64_t)blockIdx.x * d.nflat;
     // the last layer has no BatchNorm and only x[:, :, 0] leaves the decoder: its gradient is dxrec at position 0
     const int last = j == d.ND - 1;
+    if (last) sq_elbo_fin(d, smem);  // (the first launch of the backward pass)
     SqLds l = {0};
     SqBlocks blk;
     blk.n = 0;
@@ -1193,6 +1224,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_bh_k(SqDesc d) {
     const SqLayer& y0 = d.dec[0];
     float* prow = d.part + (int64_t)blockIdx.x * d.nflat;
     const int last = d.ND == 1;
+    if (last) sq_elbo_fin(d, smem);  // (a one-layer decoder: this is the first launch of the backward pass)
     SqLds l = {0};
     SqBlocks blk;
     blk.n = 0;
@@ -1503,6 +1535,18 @@ __global__ __launch_bounds__(256) void sq_reduce_k(const float* __restrict__ par
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (j < nflat) {
         int b = slice;
+        for (; b + 240 < rows; b += 256) {  // sixteen rows in one latency round (same order of additions as below)
+            float x[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = part[(int64_t)(b + 16 * q) * nflat + j];
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) {
+                t0 += x[q];
+                t1 += x[q + 1];
+                t2 += x[q + 2];
+                t3 += x[q + 3];
+            }
+        }
         for (; b + 48 < rows; b += 64) {
             t0 += part[(int64_t)b * nflat + j];
             t1 += part[(int64_t)(b + 16) * nflat + j];

@@ -261,6 +261,7 @@ static int sq_bind(const Ctx& c, const vae_op* ops, SqProgram* p, int training, 
     d.xrec = resolve(c, sl.r[1], (int64_t)B * d.dec[d.ND - 1].cout, "seq1d.x_rec", &ok);
     d.dxrec = nullptr; d.gmu = d.glv = nullptr; d.gscale = nullptr;
     d.has_elbo = 0; d.bce = 0; d.t_sb = d.t_se = 0; d.target = nullptr; d.egscale = nullptr; d.dxrec_w = nullptr; d.epart = nullptr;
+    d.eout = nullptr; d.efin = 0; d.eacc = 0;
     if (p->elbo >= 0) {  // the criterion runs inside the last forward phase
         const vae_op& eo = ops[p->elbo];
         const int nps = d.dec[d.ND - 1].cout;
@@ -273,6 +274,10 @@ static int sq_bind(const Ctx& c, const vae_op* ops, SqProgram* p, int training, 
         d.egscale = resolve_opt(c, eo.r[7], 1, "seq1d.elbo.gscale", &ok);
         d.dxrec_w = resolve(c, eo.r[5], (int64_t)B * nps, "seq1d.elbo.dx_rec", &ok);
         d.epart = resolve(c, eo.r[6], 2 * VAE_ELBO_BLOCKS, "seq1d.elbo.partials", &ok);
+        if (backward && (eo.flags & VAE_F_LOSS_IN_BWD)) {  // the sum of the partials rides on the first backward launch
+            d.eout = resolve(c, eo.r[4], 4, "seq1d.elbo.out", &ok);
+            d.efin = 1; d.eacc = eo.d[5];
+        }
     }
     if (backward) {
         d.dxrec = resolve(c, sl.r[3], (int64_t)B * d.dec[d.ND - 1].cout, "seq1d.dx_rec", &ok);
@@ -371,7 +376,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
         hipLaunchKernelGGL(sq_fd_k, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fd(d, j, d.SB) * sizeof(float), c.s, d, j);
         VAE_LAUNCH_CHECK("sq_fd_k");
     }
-    if (p->elbo >= 0) {  // fixed-order sum of the workgroups' {recon, kld} partials -> out[0..3]
+    if (p->elbo >= 0 && !(ops[p->elbo].flags & VAE_F_LOSS_IN_BWD)) {  // fixed-order sum of the workgroups' {recon, kld} partials -> out[0..3]
         const vae_op& eo = ops[p->elbo];
         bool ok = true;
         float* out = resolve(c, eo.r[4], 4, "seq1d.elbo.out", &ok);

@@ -34,6 +34,8 @@ void vae_set_error(const char* fmt, ...) {
 extern "C" const char* vae_last_error(void) { return g_err; }
 
 static int scratch_for_current_device(float** out);
+extern "C" int vae_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                   int32_t* tick, vae_stream_t stream);
 
 extern "C" int vae_check_device(void) {
     int dev = 0;
@@ -2126,6 +2128,24 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
 extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                                 int n_bases, int B, vae_stream_t stream) {
     return vae_run_backward_range(ops, n_ops, bases, base_sizes, n_bases, B, stream, 0, n_ops, 1);
+}
+
+// Backward pass + Adam update of the PARAM space (bases[1]) from the GRAD space (bases[2]) as one call: what a train
+// step does after the forward (vae_run_backward, then the adam_step_k launch of vae_adam_step_hyper).  One launch that
+// both sums a fused 1-D program's gradient rows and applies Adam was measured and dropped: 15 us against 5.5 + 8 us
+// for the two launches (the update's loads and stores wait behind the row sum in every one of ~800 workgroups).
+extern "C" int vae_run_backward_step(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
+                                     int n_bases, int B, vae_stream_t stream, float* adam_m, float* adam_v,
+                                     const float* hyper, int32_t* tick) {
+    if (!adam_m || !adam_v || !hyper || !tick) VAE_FAIL(VAE_EINVAL, "backward_step: null optimiser state");
+    Ctx c;
+    int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
+    if (rc) return rc;
+    if (bases[1] == nullptr || bases[2] == nullptr || base_sizes[1] != base_sizes[2] || base_sizes[1] < 1)
+        VAE_FAIL(VAE_EINVAL, "backward_step needs the PARAM (1) and GRAD (2) spaces bound, equally large");
+    rc = vae_run_backward_range(ops, n_ops, bases, base_sizes, n_bases, B, stream, 0, n_ops, 1);
+    if (rc) return rc;
+    return vae_adam_step_hyper(bases[1], bases[2], adam_m, adam_v, base_sizes[1], hyper, tick, stream);
 }
 
 extern "C" int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat) {

@@ -188,8 +188,8 @@ class FusedTrainStep:
             L.check(L.lib().vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
         ext = [self.x.view(self.B, -1), self.eps]
         self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
-        self.prog.backward(self.work, self.flat, self.grads, self.sflat, ext, stream=stream)
-        self.opt.launch(self.group, self.flat, self.grads, self.m, self.v, self.tick, stream=stream, hyper=self.hyper)
+        self.prog.backward_step(self.work, self.flat, self.grads, self.sflat, ext, self.m, self.v, self.hyper, self.tick,
+                                stream=stream)
 
     def _refresh_hyper(self):
         g = self.group
