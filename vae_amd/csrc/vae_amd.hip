@@ -1610,9 +1610,16 @@ static int reparam_backward(const Ctx& c, const vae_op& op) {
 
 // ---- a run of LINEAR / REPARAM ops as one launch (fc.h) ---------------------------------------
 #define FC_LDS_MAX_FLOATS 16384  // 64 KB of dynamic LDS
-static int fc_enabled() {  // read once per run (make_ctx), so that a test can compare the two paths in one process
+// Read once per run (make_ctx), so that a test can compare the two paths in one process.  VAE_AMD_FC=0: off, =1: on;
+// unset: on up to FC_AUTO_MAX_BATCH samples.  The run is latency-bound at small batches (where one launch instead of
+// twelve wins: 4096 samples 97 -> 62 us, 8192 samples 2 % of the step) and bound by the weights every 16-row workgroup
+// streams from L2 at large ones (65,536 samples: 2.7 % of the step slower than op by op; break-even at 16,384).
+#define FC_AUTO_MAX_BATCH 12288
+static int fc_enabled(int B) {
+    if (g_bf16) return 0;
     const char* e = getenv("VAE_AMD_FC");
-    return !(e != nullptr && e[0] == '0') && !g_bf16;
+    if (e != nullptr && e[0] != 0) return e[0] != '0';
+    return B <= FC_AUTO_MAX_BATCH;
 }
 static inline bool fc_kind(const vae_op& op) { return op.kind == VAE_OP_LINEAR || op.kind == VAE_OP_REPARAM; }
 
@@ -1953,7 +1960,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     if (n_bases < 4 || n_bases > 128) VAE_FAIL(VAE_EINVAL, "n_bases=%d out of range", n_bases);
     if (B < 1 || B > (1 << 24)) VAE_FAIL(VAE_EINVAL, "batch %d out of range", B);
     c->bases = bases; c->sizes = sizes; c->n_bases = n_bases; c->B = B; c->s = (hipStream_t)stream;
-    c->fc = fc_enabled();
+    c->fc = fc_enabled(B);
     c->last_blocks = 0;
     c->lin_wg.n = 0;
     c->wg_fin.n = 0;
