@@ -126,9 +126,13 @@ int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const in
                      int n_bases, int B, vae_stream_t stream);
 /* vae_run_backward followed by the Adam update (train.py:51-53: loss.backward(); optimizer.step()) of the PARAM space
  * bases[1] from the GRAD space bases[2]: m, v = Adam's moments, hyper = device {lr, beta1, beta2, eps}, tick as in
- * vae_adam_step_hyper.  One host call for everything behind the forward pass of a train step. */
+ * vae_adam_step_hyper.  One host call for everything behind the forward pass of a train step.  next_eps (optional,
+ * with rng as in vae_randn): the Adam launch, the last of the step, also draws the next_eps_n standard normals of the
+ * NEXT step's reparameterisation (vae.py:15-18 draws them with randn_like at every forward), the same numbers from the
+ * same state that a vae_randn call at this point would give: a step then has no launch of its own for the noise. */
 int vae_run_backward_step(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases,
-                          int B, vae_stream_t stream, float* adam_m, float* adam_v, const float* hyper, int32_t* tick);
+                          int B, vae_stream_t stream, float* adam_m, float* adam_v, const float* hyper, int32_t* tick,
+                          float* next_eps, int64_t next_eps_n, uint64_t* rng);
 /* Backward over ops[op_begin, op_end) only (in reverse), with every weight gradient of the range complete when
  * the call's work is: a data-parallel host runs the decoder's range first, starts the all-reduce of that bucket
  * of the GRAD buffer on a side stream, and runs the encoder's range meanwhile (no counterpart in the reference,

@@ -197,3 +197,35 @@ def test_eval_forward_of_1d_models_runs_as_phases():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-3)
     print(f"eval forward B={B}: phases {times[0] * 1e3:.3f} ms, per layer {times[1] * 1e3:.3f} ms")
     assert times[0] <= 1.05 * times[1], times
+
+
+@pytest.mark.parametrize("family,use_graph", [("mnist", True), ("mnist", False), ("multiscale", True)])
+def test_next_noise_drawn_by_the_adam_launch(family, use_graph):
+    """A fused step has no launch of its own for eps: the Adam launch of step k draws the noise of step k + 1 with
+    randn_k's numbers from randn_k's state (vae_run_backward_step: next_eps).  Checked against vae_randn on a copy of
+    the state, and the state must advance exactly as one vae_randn call would have advanced it."""
+    import vae_amd
+    from vae_amd import _lib as L
+    from vae_amd.train import FusedTrainStep
+    torch.manual_seed(11)
+    if family == "mnist":
+        model, x = vae_amd.mnist_vae.VariationalAutoencoder(15), torch.rand(64, 1, 28, 28)
+    else:
+        model, x = vae_amd.multiscale_vae.vae(3, 60, 15), 50 + 10 * torch.randn(64, 3, 60)
+    model = model.to(DEV).train()
+    st = FusedTrainStep(model, vae_amd.optim.Adam(model.parameters(), lr=1e-3), 64, DEV, use_graph=use_graph)
+    x = x.to(DEV)
+    st.step(x)  # draws the first noise with a launch of its own, and the second inside Adam
+    for _ in range(3):
+        torch.cuda.synchronize()
+        state = st.rng.clone()
+        used = st.eps.clone()
+        st.step(x)
+        torch.cuda.synchronize()
+        assert not torch.equal(st.eps, used)                      # fresh noise for the coming step
+        want = torch.empty_like(st.eps)
+        L.check(L.lib().vae_randn(L.ptr(want), want.numel(), L.ptr(state), L.stream_ptr()), "vae_randn")
+        torch.cuda.synchronize()
+        assert torch.equal(st.eps, want)
+        assert torch.equal(st.rng.cpu()[:2], state.cpu()[:2])     # {seed, offset} advanced alike
+    assert abs(float(st.eps.mean())) < 0.1 and abs(float(st.eps.std()) - 1.0) < 0.1

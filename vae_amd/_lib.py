@@ -59,7 +59,7 @@ def lib():
                                          i32, i32, i32]
     L.vae_set_collective.argtypes = [ALLGATHER_FN, vp, i32, i32]
     L.vae_run_backward_step.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
-                                        vp, vp, vp, vp]
+                                        vp, vp, vp, vp, vp, i64, vp]
     L.vae_conv_fused_ok.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_dp_unique_id.argtypes = [ctypes.c_char_p, vp]
     L.vae_dp_init.argtypes = [ctypes.c_char_p, vp, i32, i32]

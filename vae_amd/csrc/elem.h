@@ -171,6 +171,39 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
         }
 }
 
+// ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+}
+// four standard normals per Philox counter base + q (Box-Muller on the four words): the body of randn_k, shared with
+// adam_step_k's draw of the next step's eps
+__device__ __forceinline__ void randn_quad(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t base, int64_t q) {
+    const uint64_t ctr = base + (uint64_t)q;
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5eed0001u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    float s0, cs0, s1, cs1;
+    sincosf(6.2831853071795865f * u1, &s0, &cs0);
+    sincosf(6.2831853071795865f * u3, &s1, &cs1);
+    const float v[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * q + j < n) out[4 * q + j] = v[j];
+}
 // ---- Adam ----------------------------------------------------------------------------------
 // tick block (device): {int32 step count t, int32 workgroups done, float 1-b1^t, float 1-b2^t}.  Every workgroup
 // reads t and works with t+1; the last one to finish (a device-scope counter) stores t+1, so a captured graph
@@ -191,8 +224,13 @@ __device__ __forceinline__ double adam_ipow(double b, int t) {
 __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float beta1, float beta2, float eps, int32_t* tick,
-                                                   const float* __restrict__ hyper) {
+                                                   const float* __restrict__ hyper, float* __restrict__ draw_out = nullptr,
+                                                   int64_t draw_n = 0, uint64_t* __restrict__ rng = nullptr) {
+    // draw_out: the NEXT step's reparameterisation noise is drawn here (randn_k's numbers from randn_k's state), so a
+    // train step has no launch of its own for it; this is the step's last kernel, nothing reads the old noise any more
     __shared__ float sbc[2];
+    uint64_t r_seed = 0, r_base = 0;
+    if (draw_out != nullptr) { r_seed = rng[0]; r_base = rng[1]; }
     if (hyper != nullptr) {
         lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3];
     }
@@ -219,53 +257,31 @@ __global__ __launch_bounds__(256) void adam_step_k(float* __restrict__ p, const 
         i += stride;
         if (i < n) { gi = g[i]; m0 = m[i]; v0 = v[i]; p0 = p[i]; }
     }
+    const int64_t nquad = (draw_n + 3) / 4;
+    if (draw_out != nullptr) {
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride)
+            randn_quad(draw_out, draw_n, r_seed, r_base, q);
+        __syncthreads();  // (the ticket below is taken after every thread of this workgroup has drawn)
+    }
     if (threadIdx.x == 0) {
-        if (atomicAdd(&tick[1], 1) == (int)gridDim.x - 1) {  // every other workgroup has read tick[0] long ago
+        if (atomicAdd(&tick[1], 1) == (int)gridDim.x - 1) {  // every other workgroup has read tick[0] (and rng[1]) long ago
             float* bc = reinterpret_cast<float*>(tick) + 2;
             bc[0] = sbc[0];
             bc[1] = sbc[1];
             tick[1] = 0;
             tick[0] = t;
+            if (draw_out != nullptr) rng[1] = r_base + (uint64_t)nquad;
         }
     }
 }
 
-// ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
-                                             uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1;
-    c3 = (uint32_t)p0;
-    c0 = n0;
-    c2 = n2;
-}
 // rng (device): {seed, offset, workgroups done}.  The offset is advanced by the last workgroup to finish (every
 // other one has read it by then), so a draw is one launch.
 __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, int64_t n, uint64_t* __restrict__ rng) {
     const uint64_t seed = rng[0], base = rng[1];
     const int64_t nquad = (n + 3) / 4;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t ctr = base + (uint64_t)q;
-        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5eed0001u, c3 = 0u;
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
-        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
-        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
-        float s0, cs0, s1, cs1;
-        sincosf(6.2831853071795865f * u1, &s0, &cs0);
-        sincosf(6.2831853071795865f * u3, &s1, &cs1);
-        const float v[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (4 * q + j < n) out[4 * q + j] = v[j];
-    }
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x)
+        randn_quad(out, n, seed, base, q);
     __syncthreads();  // (rng[1] was read by every thread of this workgroup)
     if (threadIdx.x == 0) {
         unsigned long long* done = reinterpret_cast<unsigned long long*>(rng + 2);

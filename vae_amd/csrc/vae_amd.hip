@@ -2143,8 +2143,10 @@ extern "C" int vae_run_backward(const vae_op* ops, int n_ops, float* const* base
 // for the two launches (the update's loads and stores wait behind the row sum in every one of ~800 workgroups).
 extern "C" int vae_run_backward_step(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                                      int n_bases, int B, vae_stream_t stream, float* adam_m, float* adam_v,
-                                     const float* hyper, int32_t* tick) {
+                                     const float* hyper, int32_t* tick, float* next_eps, int64_t next_eps_n,
+                                     uint64_t* rng) {
     if (!adam_m || !adam_v || !hyper || !tick) VAE_FAIL(VAE_EINVAL, "backward_step: null optimiser state");
+    if (next_eps != nullptr && (rng == nullptr || next_eps_n < 1)) VAE_FAIL(VAE_EINVAL, "backward_step: next_eps needs its size and the rng state");
     Ctx c;
     int rc = make_ctx(&c, ops, n_ops, bases, base_sizes, n_bases, B, stream);
     if (rc) return rc;
@@ -2152,7 +2154,10 @@ extern "C" int vae_run_backward_step(const vae_op* ops, int n_ops, float* const*
         VAE_FAIL(VAE_EINVAL, "backward_step needs the PARAM (1) and GRAD (2) spaces bound, equally large");
     rc = vae_run_backward_range(ops, n_ops, bases, base_sizes, n_bases, B, stream, 0, n_ops, 1);
     if (rc) return rc;
-    return vae_adam_step_hyper(bases[1], bases[2], adam_m, adam_v, base_sizes[1], hyper, tick, stream);
+    hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(base_sizes[1])), dim3(256), 0, c.s, bases[1], (const float*)bases[2], adam_m,
+                       adam_v, base_sizes[1], 0.f, 0.f, 0.f, 0.f, tick, hyper, next_eps, next_eps_n, rng);
+    VAE_LAUNCH_CHECK("adam_step_k");
+    return VAE_OK;
 }
 
 extern "C" int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat) {

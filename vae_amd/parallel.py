@@ -171,6 +171,9 @@ class DataParallelTrainStep(FusedTrainStep):
             self._hook_error = e
             return 1
 
+    def _first_eps(self):
+        pass  # (this stepper draws its noise at the head of every step, from its own per-rank state)
+
     def _enqueue_native(self, stream):
         """Everything is enqueued from here in stream order: kernels and SyncBN all-gathers on `stream`, the gradient
         buckets' all-reduces on the communication stream between two events each, Adam behind the last of them."""

@@ -289,12 +289,14 @@ class CompiledProgram:
                                          stream if stream is not None else L.stream_ptr()),
                 "vae_run_backward")
 
-    def backward_step(self, work, params, grads, state, ext, m, v, hyper, tick, stream=None):
-        """Backward pass + Adam update of `params` (vae_run_backward_step); hyper = device {lr, beta1, beta2, eps}."""
+    def backward_step(self, work, params, grads, state, ext, m, v, hyper, tick, stream=None, next_eps=None, rng=None):
+        """Backward pass + Adam update of `params` (vae_run_backward_step); hyper = device {lr, beta1, beta2, eps}.
+        next_eps / rng: the Adam launch also draws the next step's noise into next_eps."""
         self._bind(work, params, grads, state, ext)
         L.check(L.lib().vae_run_backward_step(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                               stream if stream is not None else L.stream_ptr(), L.ptr(m), L.ptr(v),
-                                              L.ptr(hyper), L.ptr(tick)),
+                                              L.ptr(hyper), L.ptr(tick), L.ptr(next_eps),
+                                              next_eps.numel() if next_eps is not None else 0, L.ptr(rng)),
                 "vae_run_backward_step")
 
     def backward_range(self, work, params, grads, state, ext, begin, end, zero_grads, stream=None):

@@ -173,6 +173,7 @@ class FusedTrainStep:
         self.hyper = torch.zeros(4, device=self.device)
         self._hyper_host = None
         self.inject_eps = False  # tests set this and fill self.eps themselves
+        self._eps_ready = False  # self.eps holds the noise drawn for the coming step
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0
@@ -184,12 +185,20 @@ class FusedTrainStep:
             p.grad = self.grads[o:o + p.numel()].view(p.shape)
 
     def _enqueue(self, stream):
-        if not self.inject_eps:
-            L.check(L.lib().vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), stream), "vae_randn")
+        # the noise of a step is drawn by the Adam launch of the step before it (no launch of its own); the first step
+        # after construction, or after the caller injected its own eps, draws it here, outside any captured graph
         ext = [self.x.view(self.B, -1), self.eps]
         self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
+        draw = not self.inject_eps
         self.prog.backward_step(self.work, self.flat, self.grads, self.sflat, ext, self.m, self.v, self.hyper, self.tick,
-                                stream=stream)
+                                stream=stream, next_eps=self.eps if draw else None, rng=self.rng if draw else None)
+
+    def _first_eps(self):
+        if self.inject_eps:
+            self._eps_ready = False
+        elif not self._eps_ready:
+            L.check(L.lib().vae_randn(L.ptr(self.eps), self.eps.numel(), L.ptr(self.rng), L.stream_ptr()), "vae_randn")
+            self._eps_ready = True
 
     def _refresh_hyper(self):
         g = self.group
@@ -220,6 +229,7 @@ class FusedTrainStep:
             raise L.VaeAmdError(f"this fused step was built under compute dtype {self.dtype}; "
                                 f"the current one is {L.get_compute_dtype()} (build a new stepper)")
         self._refresh_hyper()
+        self._first_eps()
         if self.use_graph:
             if self.graph is None or self._captured_inject != self.inject_eps:
                 if self.graph is not None:
