@@ -226,7 +226,7 @@ def roofline_seq1d(stepper, iters, model_name):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": f"{kname} (phase {top['phase']})",
             "avg_launch_us": top["avg_us"], "algorithmic_bytes_per_launch": top["algorithmic_bytes"],
-            "launches_per_step": len(phases) + (2 if not stepper.inject_eps else 1),  # + randn + adam
+            "launches_per_step": len(phases) + 1,  # + Adam (which also draws the next step's eps)
             "all_phases": phases, "all_phases_GBps": tot_b / (tot_us * 1e-6) / 1e9,
             "timing": f"HIP events on the launch stream, {iters} eager forward+backward passes"}
 
