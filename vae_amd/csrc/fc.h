@@ -35,7 +35,9 @@
 #define FC_THREADS (FC_WAVES * 64)
 #define FC_MAX_STAGES 12
 #define FC_MAX_ITEMS 24
+#ifndef FC_U
 #define FC_U 9  // k-steps (of 16) per chunk (a multiple of 3: the A rows are read three k-steps at a time)
+#endif
 
 enum { FC_LOAD = 0, FC_GEMM = 1, FC_REPARAM_FWD = 2, FC_REPARAM_BWD = 3 };
 

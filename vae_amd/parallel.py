@@ -131,8 +131,18 @@ class DataParallelTrainStep(FusedTrainStep):
         self.coll = Collective(group)
         self.native = (self.coll.backend == "nccl" and self.device.type == "cuda") if native is None else bool(native)
         self.hook_calls = 0  # SyncBN callbacks into Python (0 on the native path)
-        if self.native:
+        if self.native and native is None:
+            # auto mode: a librccl that cannot be opened or joined sends every rank (they fail alike) back to the
+            # torch.distributed callback path instead of ending the job
+            try:
+                native_init(group, self.device)
+            except L.VaeAmdError as e:
+                import sys
+                print(f"vae_amd.parallel: native RCCL path unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
+                self.native = False
+        elif self.native:
             native_init(group, self.device)
+        if self.native:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.use_graph = bool(use_graph)
         elif use_graph:
