@@ -10,7 +10,9 @@
 //                 forward (A' = x, W'(k,n) = W[n][k]) and input gradient
 //                 (A' = dY * act'(Y) taken on load, W'(k,n) = W[k][n]).
 //   lin_wgrad_k : dW[n][k] += sum_b dY'[b][n] * X[b][k],  db[n] += sum_b dY'[b][n]
-//                 (K of the MFMA = batch).  Every batch slice (workgroup column gx) writes its tile into its own
+//                 (K of the MFMA = batch; 64 x 64 output tile per workgroup, a wave = 16 rows x 4 column tiles: the
+//                 launch is bound by re-reads of X / dY through L2, which the wider tile cuts by a quarter: 34.5 ->
+//                 31.4 us for the notebook model's five layers).  Every batch slice (workgroup column gx) writes its tile into its own
 //                 row of the layer's partial region; wgrad_finalize_k adds the rows in a fixed order, so the
 //                 gradient is bit-identical from run to run (no float atomics).
 #pragma once
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
 
 // ---- weight / bias gradient ----------------------------------------------------------------
 #define LW_BB 64   // samples per staged chunk
-#define LW_YS 48   // row strides == 16 (mod 32): the four k-rows of an MFMA step hit disjoint banks
+#define LW_BN 64   // output rows (n) per workgroup: one 16-row tile per wave, each against the four 16-column k-tiles
+#define LW_YS 80   // row strides == 16 (mod 32): the four k-rows of an MFMA step hit disjoint banks
 #define LW_XS 80
 
 struct LinWgArgs {
@@ -209,7 +212,7 @@ struct LinWgArgs {
     int act;
     float slope;
     int chunks_per_block;  // consecutive LW_BB-sample chunks handled by one workgroup
-    int gx, gy, gz;        // workgroups of this layer: batch slices x 32-row tiles x 64-column tiles
+    int gx, gy, gz;        // workgroups of this layer: batch slices x 64-row tiles x 64-column tiles
     int first_block;       // of this layer in the flattened grid
 };
 
@@ -224,7 +227,7 @@ struct LinWgMulti {
 
 template <bool BF>
 __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
-    __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+32)
+    __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+64)
     __shared__ float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
     int layer = 0;
 #pragma unroll
@@ -235,9 +238,10 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     const int bx = bid % a.gx, by = (bid / a.gx) % a.gy, bz = bid / (a.gx * a.gy);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int n0 = by * 32, k0 = bz * 64;
-    const int nt = wid & 1, kt0 = (wid >> 1) * 2;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int n0 = by * LW_BN, k0 = bz * 64;
+    const int nt = wid;  // this wave's 16 output rows; it keeps all four k-tiles (a 64 x 64 block tile: X is read once
+                         // per 64 output rows and dY once per 64 columns, 3/4 of the traffic of 32 x 64)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
     // Chunks are software-pipelined: the global loads of chunk i+1 are issued (into registers) before the
@@ -245,13 +249,13 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     const int c_first = bx * a.chunks_per_block;
     const int c_end = min(c_first + a.chunks_per_block, (a.B + LW_BB - 1) / LW_BB);
     const bool has_act = a.act != VAE_ACT_NONE;
-    float vy[8], vyy[8], vx[16];
-    auto load_chunk = [&](int ch) {  // 64 rows x 32 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
+    float vy[16], vyy[16], vx[16];
+    auto load_chunk = [&](int ch) {  // 64 rows x 64 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
         const int b0 = ch * LW_BB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = tid + j * LIN_THREADS;  // 2048 = 64 x 32
-            const int r = e >> 5, c = e & 31;
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + j * LIN_THREADS;  // 4096 = 64 x 64
+            const int r = e >> 6, c = e & 63;
             vy[j] = 0.f;
             vyy[j] = 0.f;
             if (b0 + r < a.B && n0 + c < a.N) {
@@ -270,9 +274,9 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     for (int ch = c_first; ch < c_end; ++ch) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int e = tid + j * LIN_THREADS;
-            Ys[(e >> 5) * LW_YS + (e & 31)] = has_act ? vy[j] * act_grad_from_out(vyy[j], a.act, a.slope) : vy[j];
+            Ys[(e >> 6) * LW_YS + (e & 63)] = has_act ? vy[j] * act_grad_from_out(vyy[j], a.act, a.slope) : vy[j];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -281,45 +285,52 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
         }
         __syncthreads();
         if (ch + 1 < c_end) load_chunk(ch + 1);
-        if (a.db != nullptr && bz == 0 && tid < 32) {
+        if (a.db != nullptr && bz == 0 && tid < LW_BN) {
             float t = 0.f;
             for (int r = 0; r < LW_BB; ++r) t += Ys[r * LW_YS + tid];
             bsum += t;
         }
         if constexpr (BF) {  // sixteen samples per bf16 MFMA: this lane's are b16 + lk*4 + 0..3
             const float* ypb = Ys + lk * 4 * LW_YS + nt * 16 + li;
-            const float* xpb = Xs + lk * 4 * LW_XS + kt0 * 16 + li;
+            const float* xpb = Xs + lk * 4 * LW_XS + li;
 #pragma unroll
             for (int b16 = 0; b16 < LW_BB; b16 += 16) {
                 const s16x4 av = bf16_pack4(ypb[b16 * LW_YS], ypb[(b16 + 1) * LW_YS], ypb[(b16 + 2) * LW_YS], ypb[(b16 + 3) * LW_YS]);
-                const s16x4 x0 = bf16_pack4(xpb[b16 * LW_XS], xpb[(b16 + 1) * LW_XS], xpb[(b16 + 2) * LW_XS], xpb[(b16 + 3) * LW_XS]);
-                const s16x4 x1 = bf16_pack4(xpb[b16 * LW_XS + 16], xpb[(b16 + 1) * LW_XS + 16], xpb[(b16 + 2) * LW_XS + 16],
-                                            xpb[(b16 + 3) * LW_XS + 16]);
-                acc0 = MFMA_BF16(av, x0, acc0);
-                acc1 = MFMA_BF16(av, x1, acc1);
+                auto xq = [&](int c) {
+                    return bf16_pack4(xpb[b16 * LW_XS + c], xpb[(b16 + 1) * LW_XS + c], xpb[(b16 + 2) * LW_XS + c],
+                                      xpb[(b16 + 3) * LW_XS + c]);
+                };
+                acc0 = MFMA_BF16(av, xq(0), acc0);
+                acc1 = MFMA_BF16(av, xq(16), acc1);
+                acc2 = MFMA_BF16(av, xq(32), acc2);
+                acc3 = MFMA_BF16(av, xq(48), acc3);
             }
         } else {
         const float* yp = Ys + lk * LW_YS + nt * 16 + li;
-        const float* xp = Xs + lk * LW_XS + kt0 * 16 + li;
+        const float* xp = Xs + lk * LW_XS + li;
 #pragma unroll 4
         for (int b4 = 0; b4 < LW_BB; b4 += 4) {
             const float av = yp[b4 * LW_YS];
-            const float x0 = xp[b4 * LW_XS], x1 = xp[b4 * LW_XS + 16];
+            const float x0 = xp[b4 * LW_XS], x1 = xp[b4 * LW_XS + 16], x2 = xp[b4 * LW_XS + 32], x3 = xp[b4 * LW_XS + 48];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x1, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x2, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, x3, acc3, 0, 0, 0);
         }
         }
     }
     float* const prow = a.part + (int64_t)bx * ((int64_t)a.N * a.K + a.N);
-    if (a.db != nullptr && bz == 0 && tid < 32 && n0 + tid < a.N) prow[(int64_t)a.N * a.K + n0 + tid] = bsum;
+    if (a.db != nullptr && bz == 0 && tid < LW_BN && n0 + tid < a.N) prow[(int64_t)a.N * a.K + n0 + tid] = bsum;
     // D: row (n) = lk*4 + r, col (k) = li
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + nt * 16 + lk * 4 + r;
-        const int k = k0 + kt0 * 16 + li;
+        const int k = k0 + li;
         if (n < a.N) {
             if (k < a.K) prow[(int64_t)n * a.K + k] = acc0[r];
             if (k + 16 < a.K) prow[(int64_t)n * a.K + k + 16] = acc1[r];
+            if (k + 32 < a.K) prow[(int64_t)n * a.K + k + 32] = acc2[r];
+            if (k + 48 < a.K) prow[(int64_t)n * a.K + k + 48] = acc3[r];
         }
     }
 }

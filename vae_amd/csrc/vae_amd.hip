@@ -1423,13 +1423,13 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
 struct LinWgPlan { int gx, gy, gz, chunks_per_block; };
 static LinWgPlan lin_wgrad_plan(int B, int N, int K) {
     LinWgPlan p;
-    const int tiles = ((N + 31) / 32) * ((K + 63) / 64);
+    const int tiles = ((N + LW_BN - 1) / LW_BN) * ((K + 63) / 64);
     const int nch = (B + LW_BB - 1) / LW_BB;
     int gx = (512 + tiles - 1) / tiles;
     if (gx > nch) gx = nch;
     p.chunks_per_block = (nch + gx - 1) / gx;
     p.gx = (nch + p.chunks_per_block - 1) / p.chunks_per_block;
-    p.gy = (N + 31) / 32; p.gz = (K + 63) / 64;
+    p.gy = (N + LW_BN - 1) / LW_BN; p.gz = (K + 63) / 64;
     return p;
 }
 extern "C" int64_t vae_linear_wgrad_partial_floats(const vae_op* op, int B) {
