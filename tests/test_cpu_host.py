@@ -185,3 +185,33 @@ def test_device_window_loader_has_no_cpu_path():
         loader.gather(torch.arange(4))
     with pytest.raises(ValueError):
         DeviceSlidingWindow(data[:, :60], 60, device="cpu")       # T must exceed L
+
+
+def test_data_parallel_entry_points_fail_cleanly_without_a_communicator():
+    """vae_dp_* before vae_dp_init: no communicator, every call answers with an error code and a message (host-only:
+    nothing here touches a GPU or opens librccl)."""
+    import ctypes
+    from vae_amd import _lib as L
+    lib = L.lib()
+    assert lib.vae_dp_world() == 0
+    assert lib.vae_dp_enable(0) == 0                       # removing the hook is always fine
+    assert lib.vae_dp_enable(1) != 0 and b"vae_dp_init" in lib.vae_last_error()
+    buf = (ctypes.c_float * 8)()
+    assert lib.vae_dp_all_reduce_sum(buf, 8, None) != 0 and b"communicator" in lib.vae_last_error()
+    assert lib.vae_dp_all_reduce_sum(None, 8, None) != 0
+    assert lib.vae_dp_all_gather_rows(None, 4, None) != 0
+    assert lib.vae_dp_init(None, None, 0, 1) != 0          # null id
+    ident = (ctypes.c_ubyte * L.DP_ID_BYTES)()
+    assert lib.vae_dp_init(None, ident, 3, 2) != 0         # rank outside the world
+    assert lib.vae_dp_shutdown() == 0                      # nothing to destroy
+
+
+def test_backward_step_rejects_missing_optimiser_state():
+    import ctypes
+    from vae_amd import _lib as L
+    lib = L.lib()
+    ops = (L.VaeOp * 1)()
+    bases = (ctypes.c_void_p * 4)()
+    sizes = (ctypes.c_int64 * 4)()
+    rc = lib.vae_run_backward_step(ops, 0, bases, sizes, 4, 8, None, None, None, None, None, None, 0, None)
+    assert rc != 0 and b"optimiser state" in lib.vae_last_error()
