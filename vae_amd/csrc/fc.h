@@ -246,21 +246,20 @@ __global__ __launch_bounds__(FC_THREADS) void fc_chain_k(FcChain ch) {
     const int l_N = fc_u(ld0.N), l_ld = fc_u(ld0.ld_src), l_ldmy = fc_u(ld0.ldmy);
     const fc_gcp l_src = fc_u(ld0.src), l_y = fc_u(ld0.mulY);
     const bool reg_load = (it0 >> 12) == FC_IT_ELEM && fc_u(ld0.kind) == FC_LOAD && FC_ROWS * l_N <= LR * FC_THREADS;
-    if (reg_load) {
+    if (reg_load) {  // (unconditional loads with clamped indices, as in fc_fetch: the wait for them can then leave the
+                     // weights requested behind them in flight)
+        const fc_gcp yq = l_y != nullptr ? l_y : l_src;
+        const int ldy = l_y != nullptr ? l_ldmy : l_ld;
 #pragma unroll
         for (int q = 0; q < LR; ++q) {
-            const int e = tid + q * FC_THREADS;
-            const int row = e / l_N, c = e - row * l_N, m = m0 + row;
-            lr[q] = 0.f;
-            ly[q] = 1.f;
-            if (e < FC_ROWS * l_N && m < B) {
-                lr[q] = l_src[(int64_t)m * l_ld + c];
-                if (l_y != nullptr) ly[q] = l_y[(int64_t)m * l_ldmy + c];
-            }
+            const int e = min(tid + q * FC_THREADS, FC_ROWS * l_N - 1);
+            const int row = e / l_N, c = e - row * l_N, m = min(m0 + row, B - 1);
+            lr[q] = l_src[(int64_t)m * l_ld + c];
+            ly[q] = yq[(int64_t)m * ldy + c];
         }
     }
-    if (ci < nit) fc_fetch<VEC>(ch, item_at(ci), 0, 0, P, pb, pm, m0, li, lk);
     for (int e = tid; e < fc_u(ch.lds_floats); e += FC_THREADS) fc_lds[e] = 0.f;  // the padding columns stay zero
+    if (ci < nit) fc_fetch<VEC>(ch, item_at(ci), 0, 0, P, pb, pm, m0, li, lk);
     lds_barrier();
     IG_T();
     if (reg_load) {
@@ -271,8 +270,8 @@ __global__ __launch_bounds__(FC_THREADS) void fc_chain_k(FcChain ch) {
             const int e = tid + q * FC_THREADS;
             const int row = e / l_N, c = e - row * l_N;
             if (e < FC_ROWS * l_N) {
-                float v = lr[q];
-                if (l_y != nullptr && m0 + row < B) v *= act_grad_from_out(ly[q], m_act, m_slope);
+                float v = m0 + row < B ? lr[q] : 0.f;
+                if (l_y != nullptr) v *= act_grad_from_out(ly[q], m_act, m_slope);
                 fc_lds[o_off + row * o_str + c] = v;
             }
         }
