@@ -28,7 +28,29 @@ def pytest_configure(config):
 HATCH = {"grad_elements": 0, "grad_fp64_hatch": 0, "grad_kink_hatch": 0, "param_elements": 0, "param_stragglers": 0}
 
 
+# Session ceilings: a regression that pushes many elements through a hatch FAILS the session instead of printing.
+# (last full GPU run: 9 + 35 of 1,268,177 gradient elements = 7e-6 and 2.8e-5)
+HATCH_CEILING = 1e-4
+
+
+def hatch_over_ceiling():
+    n = HATCH["grad_elements"]
+    return [name for name in ("grad_fp64_hatch", "grad_kink_hatch") if n and HATCH[name] > HATCH_CEILING * n]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    over = hatch_over_ceiling()
+    if over and session.exitstatus == 0:
+        session.exitstatus = 1
+
+
 def pytest_terminal_summary(terminalreporter):
+    over = hatch_over_ceiling()
+    if over:
+        terminalreporter.write_line(
+            "FAILED tolerance-hatch ceiling: %s exceeded %g x %d gradient elements (%s)"
+            % (", ".join(over), HATCH_CEILING, HATCH["grad_elements"],
+               ", ".join("%s=%d" % (k, HATCH[k]) for k in over)), red=True)
     if HATCH["grad_elements"] or HATCH["param_elements"]:
         terminalreporter.write_line(
             "tolerance hatches: of %d gradient elements %d were accepted through the fp64-truth hatch and %d as "
@@ -59,7 +81,7 @@ def golden_case(request):
     return stem, family, kw, load_golden(stem)
 
 
-def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None):
+def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None, kinks=True, kink_exempt=()):
     """Gradient comparison used by every parity test: rtol 1e-3 (BASELINE.json north_star)
     plus an absolute floor of atol_rel x the largest gradient magnitude in the whole model.
     The floor is needed because some gradients are pure cancellation noise in fp32 (e.g.
@@ -68,7 +90,11 @@ def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None):
     truth (optional): the same gradients from the oracle evaluated in float64.  An element that
     misses the fp32 reference by more than the tolerance is still accepted when it is at least as
     close to the float64 truth as a small multiple of the fp32 reference's OWN rounding error
-    (ill-conditioned sums over raw data of magnitude ~100: two fp32 evaluation orders differ)."""
+    (ill-conditioned sums over raw data of magnitude ~100: two fp32 evaluation orders differ).
+
+    kinks=False: the model has no activation kink (LeakyReLU slope 1.0), so the ReLU-kink hatch is closed.
+    kink_exempt: name prefixes of tensors that sit behind no activation kink (their gradient cannot change when
+    a pre-activation flips sides): the kink hatch is closed for them too."""
     import torch
 
     assert set(got) == set(want), (sorted(set(got) ^ set(want)))
@@ -85,7 +111,7 @@ def assert_grads_close(got, want, rtol=1e-3, atol_rel=2e-5, truth=None):
             HATCH["grad_fp64_hatch"] += missed - int(bad.sum())
             if missed - int(bad.sum()):
                 print(f"[hatch] grad {k}: {missed - int(bad.sum())}/{bad.numel()} elements accepted via the fp64 truth")
-            if bad.any():
+            if bad.any() and kinks and not any(k.startswith(p) for p in kink_exempt):
                 # Activation kinks: at B = 4096 a few of the ~3e6 pre-activations lie within fp32 rounding of 0, and
                 # two fp32 evaluation orders put them on different sides of the ReLU.  Each flip moves the weight
                 # gradient of its layer by one sample's contribution (a rank-one term, ~1/B of the tensor).  Such a
