@@ -197,7 +197,12 @@ int vae_set_collective(vae_allgather_fn fn, void* user, int rank, int world);
  *   vae_dp_all_reduce_sum  : in-place ncclAllReduce(SUM) of n floats on `stream` (the flat gradient buffer or a
  *                            bucket of it; the ELBO is a sum over samples, so gradients add).
  *   vae_dp_world           : world size of the communicator, 0 when there is none.
- *   vae_dp_shutdown        : destroys the communicator (and removes the hook if it is the installed one). */
+ *   vae_dp_shutdown        : destroys the communicator (and removes the hook if it is the installed one).
+ *   vae_dp_set_single_comm : (before vae_dp_init) 1 = join ONE communicator only: vae_dp_all_reduce_sum then uses the
+ *                            SyncBN communicator, and the caller must enqueue every collective on ONE stream, so no
+ *                            two RCCL kernels of this library are ever in flight together.  The fallback for systems
+ *                            where two communicators used concurrently stall; default 0 (two communicators, gradient
+ *                            buckets overlapped with the encoder's backward).  vae_dp_single_comm returns the setting. */
 #define VAE_DP_ID_BYTES 256
 int vae_dp_unique_id(const char* rccl_path, void* id256);
 int vae_dp_init(const char* rccl_path, const void* id256, int rank, int world);
@@ -206,6 +211,8 @@ int vae_dp_enable(int on);
 int vae_dp_all_gather_rows(float* buf, int64_t floats_per_rank, vae_stream_t stream);
 int vae_dp_all_reduce_sum(float* buf, int64_t n, vae_stream_t stream);
 int vae_dp_shutdown(void);
+int vae_dp_set_single_comm(int on);
+int vae_dp_single_comm(void);
 
 /* 1 if the CONV/CONVT op can run on the fused LDS-staged kernels at batch B (host-only query used by
  * the Python program builder; no GPU needed). */

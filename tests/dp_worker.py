@@ -103,12 +103,41 @@ def run_gpu(stem, family, kw):
     assert_params_close({k: v.cpu() for k, v in m.state_dict().items()}, sub(g, "sd3/"), sub(g, "grad/"), steps=3, lr=1e-3)
 
 
+def run_native_fail(bad_rank):
+    """native_init when ONE rank cannot open / join RCCL (its vae_dp_unique_id is replaced by a failing stub): every
+    rank must come out of it with the same answer and at the same point of the collective sequence -- checked by the
+    broadcast that follows, which would pair with a mismatched collective (or hang) otherwise."""
+    from vae_amd import _lib as L
+    from vae_amd.parallel import native_init
+    lib = L.lib()
+    rank = dist.get_rank()
+    if rank == int(bad_rank):
+        lib.vae_dp_unique_id = lambda path, ident: -1
+    assert native_init(required=False) == 0
+    t = torch.arange(1000.0) * (1 if rank == 0 else -1)
+    dist.broadcast(t, src=0)
+    assert torch.equal(t, torch.arange(1000.0))
+    try:
+        native_init(required=True)
+    except L.VaeAmdError as e:
+        assert ("vae_dp_unique_id failed" in str(e)) == (rank == int(bad_rank)), str(e)
+    else:
+        raise AssertionError("native_init(required=True) must raise on every rank")
+    t = torch.full((7,), float(rank))
+    dist.all_reduce(t)
+    assert torch.equal(t, torch.full((7,), float(sum(range(dist.get_world_size())))))
+    assert lib.vae_dp_world() == 0
+
+
 def main():
     mode, stem = sys.argv[1], sys.argv[2]
-    _, family, kw = next(c for c in GOLDEN_CASES if c[0] == stem)
     dist.init_process_group("gloo")
     try:
-        (run_cpu if mode == "cpu" else run_gpu)(stem, family, kw)
+        if mode == "native_fail":
+            run_native_fail(stem)
+        else:
+            _, family, kw = next(c for c in GOLDEN_CASES if c[0] == stem)
+            (run_cpu if mode == "cpu" else run_gpu)(stem, family, kw)
         dist.barrier()
         print(f"DP-OK {dist.get_rank()}", flush=True)
     finally:

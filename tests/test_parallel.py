@@ -49,6 +49,13 @@ def test_dp_recipe_cpu_gloo(stem):
     _run_world("cpu", stem)
 
 
+@pytest.mark.parametrize("bad_rank", ["0", "1"])
+def test_native_init_failure_is_agreed_on_by_every_rank(bad_rank):
+    """One rank that cannot open / join RCCL must not desynchronise the others (vae_amd.parallel.native_init): both
+    ranks fall back (required=False) or raise (required=True) together, and the next collective still pairs up."""
+    _run_world("native_fail", bad_rank, timeout=120)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("stem", ["mnist_lat15", "tcvae_c3_n3_l60_fk21", "multiscale_c3_l60"])
 def test_dp_hip_path_two_ranks(stem):

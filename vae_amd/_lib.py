@@ -68,6 +68,8 @@ def lib():
     L.vae_dp_all_gather_rows.argtypes = [vp, i64, vp]
     L.vae_dp_all_reduce_sum.argtypes = [vp, i64, vp]
     L.vae_dp_shutdown.argtypes = []
+    L.vae_dp_set_single_comm.argtypes = [i32]
+    L.vae_dp_single_comm.argtypes = []
     L.vae_conv_forward_variant.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.argtypes = [ctypes.POINTER(VaeOp), i32]
     L.vae_conv_scratch_floats.restype = i64
@@ -93,7 +95,8 @@ def lib():
     for name in ("vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_set_collective", "vae_elbo_forward",
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
-                 "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step"):
+                 "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step",
+                 "vae_dp_set_single_comm", "vae_dp_single_comm"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -105,7 +108,8 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_conv_fused_ok", "vae_conv_forward_variant", "vae_conv_scratch_floats", "vae_conv_wgrad_partial_floats", "vae_linear_wgrad_partial_floats", "vae_set_collective", "vae_run_forward", "vae_time_forward", "vae_time_seq", "vae_set_compute_dtype", "vae_get_compute_dtype", "vae_run_backward", "vae_run_backward_range", "vae_elbo_forward",
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
-           "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step")
+           "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step",
+           "vae_dp_set_single_comm", "vae_dp_single_comm")
 
 
 _DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}

@@ -747,6 +747,7 @@ static struct {
     void* comm;       // SyncBN all-gathers (on the compute stream)
     void* comm_grad;  // gradient all-reduces (on the caller's communication stream, concurrent with the former)
     int rank, world;
+    int single;       // 1: comm_grad == comm (vae_dp_set_single_comm)
 } g_dp = {};
 static std::mutex g_dp_mu;
 
@@ -810,10 +811,26 @@ extern "C" int vae_dp_init(const char* rccl_path, const void* id256, int rank, i
     memcpy(id, id128, sizeof(id));
     void *comm = nullptr, *comm_grad = nullptr;
     VAE_RCCL(g_dp.comm_init_rank(&comm, world, id[0], rank));  // on the current device; every rank calls it
-    VAE_RCCL(g_dp.comm_init_rank(&comm_grad, world, id[1], rank));
+    if (g_dp.single) {
+        comm_grad = comm;  // one communicator: the caller keeps every collective on one stream (vae_dp_set_single_comm)
+    } else {
+        const int r = g_dp.comm_init_rank(&comm_grad, world, id[1], rank);
+        if (r != 0) {
+            (void)g_dp.comm_destroy(comm);
+            VAE_FAIL(VAE_EHIP, "ncclCommInitRank (gradient communicator) failed: %s", g_dp.error_string(r));
+        }
+    }
     g_dp.comm = comm; g_dp.comm_grad = comm_grad; g_dp.rank = rank; g_dp.world = world;
     return VAE_OK;
 }
+
+extern "C" int vae_dp_set_single_comm(int on) {
+    std::lock_guard<std::mutex> lock(g_dp_mu);
+    if (g_dp.comm != nullptr) VAE_FAIL(VAE_EINVAL, "dp_set_single_comm: a communicator exists already (vae_dp_shutdown first)");
+    g_dp.single = on ? 1 : 0;
+    return VAE_OK;
+}
+extern "C" int vae_dp_single_comm(void) { return g_dp.single; }
 
 extern "C" int vae_dp_world(void) { return g_dp.comm != nullptr ? g_dp.world : 0; }
 
@@ -841,8 +858,11 @@ extern "C" int vae_dp_shutdown(void) {
     if (g_dp.comm != nullptr) {
         void *comm = g_dp.comm, *comm_grad = g_dp.comm_grad;
         g_dp.comm = g_dp.comm_grad = nullptr; g_dp.world = 0; g_dp.rank = 0;
-        VAE_RCCL(g_dp.comm_destroy(comm));
-        VAE_RCCL(g_dp.comm_destroy(comm_grad));
+        // both communicators are destroyed whatever the first call returns; the first error is reported afterwards
+        const int r0 = g_dp.comm_destroy(comm);
+        const int r1 = comm_grad != comm ? g_dp.comm_destroy(comm_grad) : 0;
+        if (r0 != 0 || r1 != 0)
+            VAE_FAIL(VAE_EHIP, "ncclCommDestroy failed: %s", g_dp.error_string(r0 != 0 ? r0 : r1));
     }
     return VAE_OK;
 }

@@ -88,27 +88,70 @@ def rccl_path():
     return p if os.path.exists(p) else ""
 
 
-def native_init(group=None, device=None):
+def _all_ranks_ok(ok, group, device=None):
+    """MIN over the ranks of a success flag: every rank learns whether ALL of them succeeded."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.cpu()[0]))
+
+
+def native_init(group=None, device=None, required=True, single_comm=None):
     """Joins the library's own RCCL communicators (include/vae_amd.h: vae_dp_*) with the ranks of `group`; rank 0's
-    id travels over torch.distributed.  Idempotent per process.  Returns the world size."""
+    id travels over torch.distributed.  Idempotent per process.  Returns the world size.
+
+    The outcome is agreed on COLLECTIVELY, so that a failure on one rank cannot desynchronise the others: every rank
+    makes the same sequence of torch.distributed calls whatever happens locally -- (1) every rank opens librccl and
+    draws an id (only rank 0's is used; the call doubles as the "can this rank load RCCL" probe), (2) the id is
+    broadcast, (3) the success flags are reduced with MIN, (4) only if every rank succeeded do the ranks enter the
+    collective vae_dp_init, (5) whose result is reduced the same way.  When some rank failed: required=True raises
+    VaeAmdError on EVERY rank, required=False returns 0 on every rank (they fall back together).
+    single_comm: True = one communicator and one stream for every collective (vae_dp_set_single_comm); None reads the
+    environment variable VAE_DP_SINGLE_COMM (default 0: two communicators, gradient buckets overlapped)."""
+    import os
     lib = L.lib()
     if lib.vae_dp_world() > 0:
         return lib.vae_dp_world()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
+    gloo = dist.get_backend(group) == "gloo"
+    dev = None
+    if not gloo or device is not None:
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+    if single_comm is None:
+        single_comm = os.environ.get("VAE_DP_SINGLE_COMM", "0") not in ("", "0")
     path = rccl_path().encode()
     ident = (ctypes.c_ubyte * L.DP_ID_BYTES)()
-    if rank == 0:
-        L.check(lib.vae_dp_unique_id(path, ident), "vae_dp_unique_id")
+    err = None
+    rc = lib.vae_dp_set_single_comm(1 if single_comm else 0)
+    if rc == 0:
+        rc = lib.vae_dp_unique_id(path, ident)
+    if rc != 0:
+        err = f"vae_dp_unique_id failed ({rc}): {lib.vae_last_error().decode()}"
     t = torch.tensor(list(ident), dtype=torch.uint8)
-    t = t.to(dev) if dist.get_backend(group) != "gloo" else t
+    t = t if gloo else t.to(dev)
     dist.broadcast(t, src=0, group=group)
-    ident = (ctypes.c_ubyte * L.DP_ID_BYTES)(*t.cpu().tolist())
-    with torch.cuda.device(dev):
-        L.check(lib.vae_dp_init(path, ident, rank, world), "vae_dp_init")
-    return world
+    ok = _all_ranks_ok(err is None, group, dev)
+    if ok:
+        ident = (ctypes.c_ubyte * L.DP_ID_BYTES)(*t.cpu().tolist())
+        with torch.cuda.device(dev):
+            rc = lib.vae_dp_init(path, ident, rank, world)
+        if rc != 0:
+            err = f"vae_dp_init failed ({rc}): {lib.vae_last_error().decode()}"
+        ok = _all_ranks_ok(err is None, group, dev)
+        if not ok:
+            lib.vae_dp_shutdown()  # the ranks that did join leave again: nobody keeps half a communicator
+    if ok:
+        return world
+    msg = err if err is not None else "another rank could not join the RCCL communicators"
+    if required:
+        raise L.VaeAmdError(f"vae_amd.parallel.native_init (rank {rank}): {msg}")
+    import sys
+    print(f"vae_amd.parallel (rank {rank}): native RCCL path unavailable ({msg}); every rank uses the "
+          "torch.distributed hook", file=sys.stderr)
+    return 0
 
 
 class DataParallelTrainStep(FusedTrainStep):
@@ -121,29 +164,29 @@ class DataParallelTrainStep(FusedTrainStep):
     slice of the flat buffer starts on RCCL's stream, and the encoder's backward runs meanwhile; the encoder's
     bucket follows.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
 
-    def __init__(self, model, optimizer, B, device, bce=None, group=None, native=None, use_graph=False):
+    def __init__(self, model, optimizer, B, device, bce=None, group=None, native=None, use_graph=False,
+                 single_comm=None):
         """native: the exchanges are enqueued by the library itself over RCCL (vae_dp_*: no Python between the kernels
         of a step; default on the nccl backend); otherwise through torch.distributed from the SyncBN callback (gloo:
         CPU tests, ranks sharing one GPU).  use_graph (native only): the whole step, collectives included, is captured
-        into one hipGraph and replayed."""
+        into one hipGraph and replayed.  single_comm (native only; None: environment variable VAE_DP_SINGLE_COMM):
+        one RCCL communicator and ONE stream for the SyncBN gathers and the gradient all-reduces -- no two collectives
+        in flight together, no overlap; the fallback should the two-communicator overlap stall on a system."""
         # (the whole-model 1-D path has no synchronised BatchNorm yet: data parallel keeps the per-layer program)
         super().__init__(model, optimizer, B, device, bce=bce, use_graph=False, allow_seq1d=False)
         self.coll = Collective(group)
         self.native = (self.coll.backend == "nccl" and self.device.type == "cuda") if native is None else bool(native)
         self.hook_calls = 0  # SyncBN callbacks into Python (0 on the native path)
         if self.native and native is None:
-            # auto mode: a librccl that cannot be opened or joined sends every rank (they fail alike) back to the
-            # torch.distributed callback path instead of ending the job
-            try:
-                native_init(group, self.device)
-            except L.VaeAmdError as e:
-                import sys
-                print(f"vae_amd.parallel: native RCCL path unavailable ({e}); using the torch.distributed hook", file=sys.stderr)
-                self.native = False
+            # auto mode: a librccl that some rank cannot open or join sends EVERY rank (native_init agrees on the
+            # outcome collectively) back to the torch.distributed callback path instead of ending the job
+            self.native = native_init(group, self.device, required=False, single_comm=single_comm) > 0
         elif self.native:
-            native_init(group, self.device)
+            native_init(group, self.device, required=True, single_comm=single_comm)
         if self.native:
-            self.comm_stream = torch.cuda.Stream(device=self.device)
+            # single-communicator mode: every collective of the step goes to the compute stream (no side stream)
+            self.single_comm = bool(L.lib().vae_dp_single_comm())
+            self.comm_stream = None if self.single_comm else torch.cuda.Stream(device=self.device)
             self.use_graph = bool(use_graph)
         elif use_graph:
             raise ValueError("use_graph needs the native RCCL path")
@@ -202,6 +245,9 @@ class DataParallelTrainStep(FusedTrainStep):
                 self.prog.backward_range(self.work, self.flat, self.grads, self.sflat, ext, begin, end, i == 0,
                                          stream=stream)
                 g = self.grads[lo:hi]
+                if self.comm_stream is None:  # single communicator: in stream order on the compute stream
+                    L.check(lib.vae_dp_all_reduce_sum(L.ptr(g), g.numel(), stream), "vae_dp_all_reduce_sum")
+                    continue
                 ready = torch.cuda.Event()
                 ready.record(cs)
                 self.comm_stream.wait_event(ready)
