@@ -46,6 +46,11 @@ def parse_args():
     ap.add_argument("--dp-graph", action="store_true",
                     help="N > 1 on RCCL: capture the data-parallel step (collectives included) into one hipGraph")
     ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--rank-timeout", type=int, default=900,
+                    help="--gpus N > 1 started by this script: seconds after which the ranks are killed (0: never)")
+    ap.add_argument("--dp-single-comm", action="store_true",
+                    help="N > 1 on RCCL: one communicator and one stream for every collective (no overlap; the fallback "
+                         "should two communicators in flight stall)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="compute dtype of the matrix kernels: f32 (the headline) or bf16 operands with fp32 accumulate "
                          "and fp32 storage (vae_set_compute_dtype; BASELINE configs[1] 'fp32 then bf16')")
@@ -74,11 +79,44 @@ def self_launch(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import shutil
+    import signal
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix="vae_bench_ranks_")
+    # stderr of every rank goes to a file of its own (stdout stays ours: rank 0's JSON line goes straight out)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    rc = subprocess.run(cmd, env=env).returncode  # children inherit stdout: rank 0's JSON line goes straight out
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--redirects", "2", "--log-dir", logdir,
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def tails(n):
+        for root, _, files in sorted(os.walk(logdir)):
+            for f in files:
+                if f == "stderr.log":
+                    with open(os.path.join(root, f), errors="replace") as fh:
+                        lines = fh.read().splitlines()[-n:]
+                    if lines:
+                        print(f"---- rank {os.path.basename(root)} stderr (last {len(lines)} lines)", file=sys.stderr)
+                        print("\n".join(lines), file=sys.stderr, flush=True)
+    try:
+        rc = proc.wait(timeout=args.rank_timeout if args.rank_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        # a rank that deadlocks in a collective never returns: this process has not touched a GPU, so it can end the
+        # ranks (their whole process group) and say what each was doing
+        print(f"bench.py: the ranks did not finish within --rank-timeout {args.rank_timeout}s: killing them",
+              file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        tails(30)
+        shutil.rmtree(logdir, ignore_errors=True)
+        sys.exit(124)
     if rc != 0:
         print(f"bench.py: a rank failed (launcher exit status {rc})", file=sys.stderr, flush=True)
+        tails(30)
+    shutil.rmtree(logdir, ignore_errors=True)
     sys.exit(rc if 0 <= rc < 256 else 1)
 
 
@@ -163,100 +201,56 @@ def pmc_traffic(model_name, kernel, B):
     return None, f"kernel {kernel} not in profiles/{os.path.basename(files[-1])}"
 
 
-def roofline_mnist(stepper, iters, bf16=False):
-    """Dominant kernel igemm_gather_k<1, 2, false, 0, BF> (the forward implicit-GEMM gather on MFMA tiles of the conv /
-    transposed-conv layers with <= 16 output channels: conv2, convT1, convT2; the largest line of
-    profiles/*kernel_stats.csv).  Its launches are timed live with HIP events on the launch stream
-    (vae_time_forward puts an event between consecutive ops; a fused conv op is exactly one launch).
-    achieved = algorithmic bytes per launch / average launch duration; algorithmic bytes of a launch =
-    4 * B * (Cin*H*W + Cout*OH*OW) + 4 * weights + bias (input read once, output written once: DESIGN.md)."""
-    from vae_amd import _lib as L
-    prog = stepper.prog
-    ext = [stepper.x.view(stepper.B, -1), stepper.eps]
-    sel = []
-    for i in range(prog.n_ops):
-        op = prog.ops[i]
-        if op.kind in (L.OP_CONV, L.OP_CONVT) and (op.flags & L.F_FUSED) and \
-                L.lib().vae_conv_forward_variant(ctypes.byref(op), stepper.B) == 100:
-            cin, H, W, cout, OH, OW, KH, KW = [op.d[j] for j in range(8)]
-            nbytes = 4 * (stepper.B * (cin * H * W + cout * OH * OW) + cin * cout * KH * KW + cout)
-            sel.append((i, nbytes))
-    if not sel:
-        return None
-    tot_ms = [0.0] * len(sel)
-    for it in range(iters + 2):
-        ms = prog.time_forward(stepper.work, stepper.flat, stepper.sflat, ext, True)
-        if it >= 2:
-            for k, (i, _) in enumerate(sel):
-                tot_ms[k] += ms[i]
-    avg_us = sum(tot_ms) / iters / len(sel) * 1e3
-    avg_bytes = sum(b for _, b in sel) / len(sel)
-    achieved = avg_bytes / (avg_us * 1e-6) / 1e9
-    kernel = "igemm_gather_k<1, 2, false, 0, true>" if bf16 else "igemm_gather_k<1, 2, false, 0, false>"
-    traffic, src = pmc_traffic("mnist", kernel, stepper.B)
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": kernel,
-            "launches_per_step": len(sel), "avg_launch_us": avg_us, "algorithmic_bytes_per_launch": avg_bytes,
-            "per_launch_us": [t / iters * 1e3 for t in tot_ms],
-            "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
-
-
-def roofline_seq1d(stepper, iters, model_name):
-    """1-D models on the fused path (seq1d.h: one launch per BatchNorm-delimited phase): every launch of forward +
-    backward is timed with HIP events on the launch stream (vae_time_seq); the dominant kernel is the phase with the
-    largest average duration.  Algorithmic bytes of a phase: its activations in and out once, weights included
-    (seq1d_host.h: sq_mark)."""
+def roofline_step(stepper, iters, model_name):
+    """Roofline of the dominant kernel FAMILY of the whole train step, whichever it is: every launch of forward +
+    backward + Adam is timed live with a HIP event behind it on the launch stream (vae_time_step; eager launches of
+    real steps, after the timed region), launches are grouped by kernel name as rocprofv3's --stats groups them, and
+    the family with the largest total time per step is reported.  achieved = the family's algorithmic bytes per step
+    (declared by each launch site from the op geometry: inputs read once, outputs written once, weights included) /
+    its time per step; matrix-bound families (wide.h) report flops against the fp32 MFMA peak instead."""
     prog = stepper.prog
     ext = [stepper.x.view(stepper.B, -1), stepper.eps]
     acc = None
     for it in range(iters + 2):
-        rows = prog.time_seq(stepper.work, stepper.flat, stepper.grads, stepper.sflat, ext)
+        rows = prog.time_step(stepper.work, stepper.flat, stepper.grads, stepper.sflat, ext, stepper.m, stepper.v,
+                              stepper.hyper, stepper.tick)
         if it >= 2:
             if acc is None:
-                acc = [[t, 0.0, b] for t, _, b in rows]
-            for a, (_, ms, _) in zip(acc, rows):
+                acc = [[n, 0.0, b, f] for n, _, b, f in rows]
+            assert len(rows) == len(acc)
+            for a, (_, ms, _, _) in zip(acc, rows):
                 a[1] += ms
-    phases = [{"phase": t, "avg_us": ms / iters * 1e3, "algorithmic_bytes": b} for t, ms, b in acc]
-    top = max(phases, key=lambda p: p["avg_us"])
-    kname = {"fe": "sq_fe_k", "fh": "sq_fh_k", "fd": "sq_fd_k", "bd": "sq_bd_k", "bh": "sq_bh_k", "be": "sq_be_k"}[top["phase"][:2]]
-    achieved = top["algorithmic_bytes"] / (top["avg_us"] * 1e-6) / 1e9
-    traffic, src = pmc_traffic(model_name, kname, stepper.B)
-    tot_us = sum(p["avg_us"] for p in phases)
-    tot_b = sum(p["algorithmic_bytes"] for p in phases)
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": f"{kname} (phase {top['phase']})",
-            "avg_launch_us": top["avg_us"], "algorithmic_bytes_per_launch": top["algorithmic_bytes"],
-            "launches_per_step": len(phases) + 1,  # + Adam (which also draws the next step's eps)
-            "all_phases": phases, "all_phases_GBps": tot_b / (tot_us * 1e-6) / 1e9,
-            "timing": f"HIP events on the launch stream, {iters} eager forward+backward passes"}
-
-
-def roofline_wide(stepper, iters):
-    """Widened model: the convolutions run on fp32 MFMA tiles (wide.h) and are matrix-bound; the dominant forward
-    launch is the conv op with the largest duration.  flops = 2 * B * Cout*OH*OW * Cin*KH*KW per launch."""
-    from vae_amd import _lib as L
-    prog = stepper.prog
-    ext = [stepper.x.view(stepper.B, -1), stepper.eps]
-    tot = [0.0] * prog.n_ops
-    for it in range(iters + 2):
-        ms = prog.time_forward(stepper.work, stepper.flat, stepper.sflat, ext, True)
-        if it >= 2:
-            tot = [a + b for a, b in zip(tot, ms)]
-    convs = [i for i in range(prog.n_ops) if prog.ops[i].kind in (L.OP_CONV, L.OP_CONVT)]
-    i = max(convs, key=lambda k: tot[k])
-    op = prog.ops[i]
-    cin, H, W, cout, OH, OW, KH, KW = [op.d[j] for j in range(8)]
-    if op.kind == L.OP_CONV:
-        flops = 2.0 * stepper.B * cout * OH * OW * cin * KH * KW
-    else:  # transposed: every input pixel meets every tap
-        flops = 2.0 * stepper.B * cin * H * W * cout * KH * KW
-    us = tot[i] / iters * 1e3
-    achieved = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": "matrix-bound kernel: see profiles/*wide_sq_counters.csv",
-            "kernel": f"wide conv op {i} ({'conv' if op.kind == L.OP_CONV else 'convT'} {cin}->{cout}, {H}x{W} -> {OH}x{OW}, k{KH})",
-            "avg_launch_us": us, "algorithmic_flops_per_launch": flops,
-            "timing": f"HIP events on the launch stream, {iters} eager forward passes"}
+    fams = {}
+    for name, ms, b, f in acc:
+        fam = name.split(" (phase")[0]
+        d = fams.setdefault(fam, {"kernel": fam, "launches_per_step": 0, "us_per_step": 0.0, "bytes_per_step": 0.0,
+                                  "flops_per_step": 0.0, "per_launch_us": []})
+        d["launches_per_step"] += 1
+        d["us_per_step"] += ms / iters * 1e3
+        d["bytes_per_step"] += b
+        d["flops_per_step"] += f
+        d["per_launch_us"].append(round(ms / iters * 1e3, 2))
+    step_us = sum(d["us_per_step"] for d in fams.values())
+    order = sorted(fams.values(), key=lambda d: -d["us_per_step"])
+    top = order[0]
+    n = top["launches_per_step"]
+    if top["flops_per_step"] > 0 and top["kernel"].startswith("wide_"):
+        achieved = top["flops_per_step"] / (top["us_per_step"] * 1e-6) / 1e12
+        out = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_launch": top["flops_per_step"] / n}
+    else:
+        achieved = top["bytes_per_step"] / (top["us_per_step"] * 1e-6) / 1e9
+        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    traffic, src = pmc_traffic(model_name, top["kernel"], stepper.B)
+    out.update({"traffic": traffic, "traffic_source": src, "kernel": top["kernel"], "launches_per_step": n,
+                "avg_launch_us": top["us_per_step"] / n, "per_launch_us": top["per_launch_us"],
+                "algorithmic_bytes_per_launch": top["bytes_per_step"] / n,
+                "share_of_step": top["us_per_step"] / step_us,
+                "step_launches": len(acc), "step_sum_of_launches_us": step_us,
+                "families": [{"kernel": d["kernel"], "launches": d["launches_per_step"], "us_per_step": round(d["us_per_step"], 2),
+                              "GBps": round(d["bytes_per_step"] / (d["us_per_step"] * 1e-6) / 1e9, 1)} for d in order[:10]],
+                "timing": f"HIP event behind every launch on the launch stream, {iters} eager train steps (vae_time_step)"})
+    return out
 
 
 # ------------------------------------------------------------------------------------------- main
@@ -326,7 +320,8 @@ def main():
         stepper = FusedTrainStep(model, opt, B, dev, use_graph=not args.no_graph)
     else:
         from vae_amd.parallel import DataParallelTrainStep
-        stepper = DataParallelTrainStep(model, opt, B, dev, use_graph=args.dp_graph and backend == "nccl")
+        stepper = DataParallelTrainStep(model, opt, B, dev, use_graph=args.dp_graph and backend == "nccl",
+                                        single_comm=True if args.dp_single_comm else None)
     stepper.step(x)
 
     def barrier():
@@ -344,15 +339,10 @@ def main():
         raise SystemExit(f"loss is {loss}: the step is not training")
 
     roof = None
-    if rank == 0 and world == 1:
-        if args.model == "mnist":
-            roof = roofline_mnist(stepper, args.roofline_iters, args.dtype == "bf16")
-        elif getattr(stepper.prog, "seq1d", False):
-            roof = roofline_seq1d(stepper, args.roofline_iters, args.model)
-        elif args.model == "wide":
-            roof = roofline_wide(stepper, args.roofline_iters)
-    elif rank == 0 and args.model == "mnist":
-        roof = roofline_mnist(stepper, args.roofline_iters, args.dtype == "bf16")  # (local launches only)
+    if rank == 0:
+        # (N > 1: this rank's launches only, BatchNorm on local statistics, no collectives; the step it takes is local too,
+        # which no longer matters behind the timed region)
+        roof = roofline_step(stepper, args.roofline_iters, args.model)
     barrier()
 
     strong_ref = None

@@ -155,6 +155,19 @@ int vae_time_forward(const vae_op* ops, int n_ops, float* const* bases, const in
 int vae_time_seq(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases, int B,
                  vae_stream_t stream, float* ms, double* bytes, char* tags, int cap, int* n_launches);
 
+/* Profiling twin of a whole train step (train.py:57-66: forward, criterion, backward, optimizer.step): the launches of
+ * vae_run_forward(training) followed by vae_run_backward_step (hyper != NULL) or vae_run_backward (hyper == NULL), with
+ * a HIP event recorded on `stream` behind EVERY kernel launch.  For launch k: ms[k] = device time between the events
+ * around it, names + 64*k = its kernel name as rocprofv3 prints it (template arguments included; fused 1-D phases also
+ * carry their phase tag), bytes[k] = algorithmic bytes (every input read once, every output written once, weights
+ * included), flops[k] = 2 x multiply-adds for the matrix-bound wide kernels (0 elsewhere).  cap = room in the arrays
+ * (names: 64 * cap chars), *n_launches = launches written.  The step is REAL (parameters, Adam state and BatchNorm
+ * statistics advance).  Synchronises the stream; not capturable.  bench.py derives its roofline line from it: the
+ * kernel family with the largest total time over the step. */
+int vae_time_step(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases, int B,
+                  vae_stream_t stream, float* adam_m, float* adam_v, const float* hyper, int32_t* tick, float* ms,
+                  double* bytes, double* flops, char* names, int cap, int* n_launches);
+
 /* Compute dtype of the matrix kernels (convolutions on the fused and wide paths, Linear layers), process-global.
  * VAE_DTYPE_F32 (default): fp32 MFMA, results within the fp32 tolerance of the reference.  VAE_DTYPE_BF16: the MFMA
  * operands are rounded to bf16 (round to nearest even) as they leave LDS, products accumulate in fp32; activations,

@@ -54,6 +54,9 @@ def lib():
     L.vae_time_seq.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, i32,
                                ctypes.POINTER(i32)]
+    L.vae_time_step.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp, vp, vp, vp, vp,
+                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                ctypes.c_char_p, i32, ctypes.POINTER(i32)]
     L.vae_run_backward.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp]
     L.vae_run_backward_range.argtypes = [ctypes.POINTER(VaeOp), i32, ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, vp,
                                          i32, i32, i32]
@@ -96,7 +99,7 @@ def lib():
                  "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
                  "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
                  "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step",
-                 "vae_dp_set_single_comm", "vae_dp_single_comm"):
+                 "vae_dp_set_single_comm", "vae_dp_single_comm", "vae_time_step"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -109,7 +112,7 @@ EXPORTS = ("vae_seq_scratch_floats", "vae_last_error", "vae_check_device", "vae_
            "vae_elbo_forward_noalloc", "vae_elbo_backward", "vae_adam_step", "vae_adam_step_hyper", "vae_randn", "vae_window_gather", "vae_graph_begin", "vae_graph_end",
            "vae_graph_launch", "vae_graph_destroy", "vae_dp_unique_id", "vae_dp_init", "vae_dp_world", "vae_dp_enable",
            "vae_dp_all_gather_rows", "vae_dp_all_reduce_sum", "vae_dp_shutdown", "vae_run_backward_step",
-           "vae_dp_set_single_comm", "vae_dp_single_comm")
+           "vae_dp_set_single_comm", "vae_dp_single_comm", "vae_time_step")
 
 
 _DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}

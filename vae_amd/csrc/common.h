@@ -19,10 +19,47 @@ void vae_set_error(const char* fmt, ...);
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) VAE_FAIL(VAE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+// ---- per-launch timing (vae_time_step) -----------------------------------------------------
+// When a timer is active on this thread, every VAE_LAUNCH_CHECK records a HIP event behind the launch it checks, ON
+// THE LAUNCH STREAM, together with the kernel's name and the algorithmic bytes (or flops) the launch site declared
+// with VAE_TNAME / VAE_TBYTES / VAE_TFLOPS just before.  Inactive (the normal case): one thread-local pointer test.
+#include <stdio.h>
+#define VAE_TIMER_NAME 64
+struct VaeTimer {
+    hipStream_t s;
+    int n, cap;
+    bool failed;
+    hipEvent_t* ev;  // cap + 1 events; ev[0] is recorded by the owner before the first launch
+    char (*names)[VAE_TIMER_NAME];
+    double* bytes;
+    double* flops;
+};
+static thread_local VaeTimer* vae_tl_timer = nullptr;
+static thread_local double vae_tl_bytes = 0.0, vae_tl_flops = 0.0;
+static thread_local char vae_tl_name[VAE_TIMER_NAME] = "";
+static inline void vae_timer_mark(const char* name) {
+    VaeTimer* t = vae_tl_timer;
+    if (t == nullptr) return;
+    if (t->n < t->cap) {
+        if (hipEventRecord(t->ev[t->n + 1], t->s) != hipSuccess) t->failed = true;
+        snprintf(t->names[t->n], VAE_TIMER_NAME, "%s", vae_tl_name[0] ? vae_tl_name : name);
+        t->bytes[t->n] = vae_tl_bytes;
+        t->flops[t->n] = vae_tl_flops;
+        ++t->n;
+    } else {
+        t->failed = true;
+    }
+    vae_tl_bytes = vae_tl_flops = 0.0;
+    vae_tl_name[0] = 0;
+}
+#define VAE_TNAME(...) do { if (vae_tl_timer != nullptr) snprintf(vae_tl_name, VAE_TIMER_NAME, __VA_ARGS__); } while (0)
+#define VAE_TBYTES(expr) do { if (vae_tl_timer != nullptr) vae_tl_bytes = (double)(expr); } while (0)
+#define VAE_TFLOPS(expr) do { if (vae_tl_timer != nullptr) vae_tl_flops = (double)(expr); } while (0)
 #define VAE_LAUNCH_CHECK(name)                                                                   \
     do {                                                                                         \
         hipError_t e_ = hipGetLastError();                                                       \
         if (e_ != hipSuccess) VAE_FAIL(VAE_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+        vae_timer_mark(name);                                                                    \
     } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

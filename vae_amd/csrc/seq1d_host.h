@@ -329,7 +329,16 @@ struct SqTimer {
     int n;
     bool failed;
 };
+static thread_local int sq_tl_nenc = 1;  // (for the kernel names of vae_time_step)
 static void sq_mark(SqTimer* tm, hipStream_t s, const char* tag, double floats) {
+    if (vae_tl_timer != nullptr) {  // vae_time_step: the launch that follows carries these bytes and the phase tag
+        VAE_TBYTES(4.0 * floats);
+        const char* kn = tag[0] == 'r' ? "sq_reduce_k" : tag[0] == 'e' ? "elbo_finalize_k" :
+                         tag[1] == 'e' ? (tag[0] == 'f' ? "sq_fe_k" : "sq_be_k") : tag[1] == 'h' ? (tag[0] == 'f' ? "sq_fh_k" : "sq_bh_k") :
+                                         (tag[0] == 'f' ? "sq_fd_k" : "sq_bd_k");
+        if (tag[0] != 'r' && tag[0] != 'e' && tag[1] != 'd') VAE_TNAME("%s<%d> (phase %s)", kn, sq_tl_nenc, tag);
+        else VAE_TNAME("%s (phase %s)", kn, tag);
+    }
     if (tm == nullptr || tm->n >= SQ_MAX_MARKS) return;
     if (hipEventRecord(tm->ev[tm->n], s) != hipSuccess) tm->failed = true;
     tm->bytes[tm->n] = 4.0 * floats;
@@ -343,6 +352,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
     if (rc) return rc;
     if ((rc = sq_grant_lds()) != VAE_OK) return rc;
     const SqDesc& d = p->d;
+    sq_tl_nenc = d.nenc;
     if (training && (int64_t)c.B * d.dec[0].lout < 2) VAE_FAIL(VAE_EINVAL, "bn: training needs more than 1 value per channel");
     const double Bd = (double)c.B;
     char tag[8];
@@ -393,6 +403,7 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* t
     if (rc) return rc;
     if ((rc = sq_grant_lds()) != VAE_OK) return rc;
     const SqDesc& d = p->d;
+    sq_tl_nenc = d.nenc;
     bool ok = true;
     float* grad = resolve(c, (int64_t)2 << 56, d.nflat, "seq1d.grad", &ok);
     if (!ok) return VAE_EINVAL;

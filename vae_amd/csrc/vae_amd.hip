@@ -181,6 +181,9 @@ static int launch_conv_gather(const Ctx& c, const float* x, const float* w, cons
             else hipLaunchKernelGGL((wide_gather_k<false, 2>), grid, dim3(WD_THREADS), 2 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         }
+        VAE_TNAME("wide_gather_k<false, %d, %s>", g.Cout <= 32 ? 1 : 2, g_bf16 ? "true" : "false");
+        VAE_TFLOPS(2.0 * (double)npix * (double)K * g.Cout);
+        VAE_TBYTES(4.0 * ((double)c.B * ((double)g.Cin * g.H * g.W + (double)g.Cout * g.OH * g.OW) + (double)K * g.Cout));
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
     }
@@ -216,6 +219,9 @@ static int launch_convT_gather(const Ctx& c, const float* x, const float* w, con
             else hipLaunchKernelGGL((wide_gather_k<true, 2>), grid, dim3(WD_THREADS), 3 * kpad * sizeof(int), c.s, x, w, bias, y,
                                c.B, g, act, slope, accumulate, kpad);
         }
+        VAE_TNAME("wide_gather_k<true, %d, %s>", g.Cout <= 32 ? 1 : 2, g_bf16 ? "true" : "false");
+        VAE_TFLOPS(2.0 * (double)c.B * g.Cin * g.H * g.W * (double)g.Cout * g.KH * g.KW);  // every input pixel meets every tap
+        VAE_TBYTES(4.0 * ((double)c.B * ((double)g.Cin * g.H * g.W + (double)g.Cout * g.OH * g.OW) + (double)g.Cin * g.Cout * g.KH * g.KW));
         VAE_LAUNCH_CHECK("wide_gather_k");
         return VAE_OK;
     }
@@ -264,6 +270,9 @@ static int launch_wgrad(const Ctx& c, const float* S, const float* G, float* dw,
         dim3 grid((unsigned)wp.chunks, wp.gy, wp.gz);
         if (g_bf16) hipLaunchKernelGGL(wide_wgrad_k<true>, grid, dim3(WD_THREADS), 0, c.s, a);
         else hipLaunchKernelGGL(wide_wgrad_k<false>, grid, dim3(WD_THREADS), 0, c.s, a);
+        VAE_TNAME("wide_wgrad_k<%s>", g_bf16 ? "true" : "false");
+        VAE_TFLOPS(2.0 * (double)R * A * (double)wp.NK);
+        VAE_TBYTES(4.0 * ((double)R * A + (double)c.B * C * GH * GW));
         VAE_LAUNCH_CHECK("wide_wgrad_k");
         if (part != nullptr) {
             const int64_t n = (int64_t)A * wp.NK;
@@ -339,6 +348,8 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     if (op.act != VAE_ACT_NONE || db != nullptr) {
         hipLaunchKernelGGL(chan_reduce_k<CR_ACTBWD>, dim3(g.Cout, nchunks), dim3(256), 0, c.s, nullptr, dy, y, nullptr,
                            part, c.B, g.Cout, g.OH * g.OW, bchunk, op.act, op.f[0], 0);
+        VAE_TNAME("chan_reduce_k<2>");
+        VAE_TBYTES(4.0 * 3.0 * (double)nout);
         VAE_LAUNCH_CHECK("chan_reduce_k<ACTBWD>");
         if (db != nullptr) {
             hipLaunchKernelGGL(bias_grad_finalize_k, dim3(g.Cout), dim3(64), 0, c.s, part, db, g.Cout,
@@ -578,6 +589,11 @@ static int flush_wgrad_finalize(const Ctx& c) {
         blocks += (m.l[i].ncols + 15) / 16;
     }
     hipLaunchKernelGGL(wgrad_finalize_k, dim3(blocks), dim3(256), 0, c.s, m);
+    if (vae_tl_timer != nullptr) {
+        double fl = 0;
+        for (int i = 0; i < m.n; ++i) fl += (double)(m.l[i].nrows + 2) * m.l[i].ncols;
+        VAE_TBYTES(4.0 * fl);
+    }
     m.n = 0;
     VAE_LAUNCH_CHECK("wgrad_finalize_k");
     return VAE_OK;
@@ -597,6 +613,9 @@ static int launch_wgrad(const Ctx& c, const WgArgs& wa, const WgPlan& wp, float*
         case 210: launch_wgrad_inst<2, 10>(c, wa, grid, bytes); break;
         default: VAE_FAIL(VAE_EINVAL, "conv wgrad: no kernel for %dx%d accumulator tiles", wp.MT, wp.NT);
     }
+    VAE_TNAME("igemm_wgrad_k<%d, %d, %s>", wp.MT, wp.NT, g_bf16 ? "true" : "false");
+    VAE_TBYTES(4.0 * (double)c.B * ((double)wa.Sc * wa.SH * wa.SW * (wa.S.mode >= TR_GRAD_BN ? 2 : 1) +
+                                    (double)wa.Gc * wa.GH * wa.GW * (wa.G.mode >= TR_GRAD_BN ? 2 : 1)));
     VAE_LAUNCH_CHECK("igemm_wgrad_k");
     // the reduction of the partials is deferred: one launch for every conv layer of the pass (flush_wgrad_finalize)
     if (c.wg_fin.n == WG_FIN_MAX_LAYERS) {
@@ -999,6 +1018,9 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
             else MIDC_ACT(true, false);
 #undef MIDC_ACT
 #undef MIDC_LAUNCH
+            VAE_TNAME("mid_conv_k<%s, %s, %d>", gradin ? "true" : "false", (gradin && epbn) ? "true" : "false", actv);
+            VAE_TBYTES(4.0 * ((double)c.B * ((double)q.Cin * q.H * q.W * (gradin ? 2 : 1) +
+                                             (double)q.N * q.OH * q.OW * ((gradin && epbn) ? 2 : 1)) + (double)q.Cin * q.KH * q.KW * q.N));
             VAE_LAUNCH_CHECK("mid_conv_k");
             if (a.slab != nullptr) c.last_blocks = grid;
             return VAE_OK;
@@ -1025,6 +1047,11 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
         if (grad) IG_LAUNCH(1, true, 0); else IG_LAUNCH(1, false, 0);
     }
 #undef IG_LAUNCH
+    VAE_TNAME("igemm_gather_k<%d, 2, %s, %d, %s>", a.g.Np > 16 ? 2 : 1, grad ? "true" : "false", a.g.Np > 16 ? 0 : nd,
+              (g_bf16 && (a.g.Np > 16 || nd == 0)) ? "true" : "false");
+    VAE_TBYTES(4.0 * ((double)c.B * ((double)a.g.Cin * a.g.H * a.g.W * (grad ? 2 : 1) +
+                                     (double)a.g.N * a.g.OH * a.g.OW * (a.ep_mode == EP_BNGRAD ? 2 : 1)) +
+                      (double)a.g.Cin * a.g.KH * a.g.KW * a.g.N));
     VAE_LAUNCH_CHECK(what);
     if (a.slab != nullptr) c.last_blocks = a.nchunks;
     return VAE_OK;
@@ -1075,6 +1102,8 @@ static int conv_forward_fused(const Ctx& c, const vae_op& op, int training) {
         t.d_W = mk_fdiv((uint32_t)t.W); t.d_W4 = mk_fdiv((uint32_t)(2 * t.W / 4));
         if (thin == 1) THIN_LAUNCH(thin_conv_fwd_k, op.act, thin_grid(c.B), thin_lds_bytes(t.H, t.W, 0), c.s, t);
         else THIN_LAUNCH(thin_convT_fwd_k, op.act, thin_grid(c.B), thin_lds_bytes(t.H, t.W, 2), c.s, t);
+        VAE_TNAME("%s<8, %d>", thin == 1 ? "thin_conv_fwd_k" : "thin_convT_fwd_k", op.act);
+        VAE_TBYTES(4.0 * ((double)nin + (double)nout + (double)nw));
         VAE_LAUNCH_CHECK("thin conv forward");
         return VAE_OK;
     }
@@ -1144,6 +1173,9 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
                 THIN_LAUNCH(thin_convT_bwd_k, op.act, grid, thin_lds_bytes(t.H, t.W, 3), c.s, t);
                 if (t.slab != nullptr) c.last_blocks = grid;
             }
+            VAE_TNAME("%s<8, %d>", thin == 1 ? "thin_conv_wgrad_k" : "thin_convT_bwd_k", op.act);
+            // conv1: x, gradient and output read once; convT3: gradient, output and input read, input gradient written
+            VAE_TBYTES(4.0 * (thin == 1 ? (double)nin + 2.0 * nout : 2.0 * nout + (double)nin * (dx != nullptr ? 2 : 1)));
             VAE_LAUNCH_CHECK("thin conv backward");
             if (c.wg_fin.n == WG_FIN_MAX_LAYERS && (rc = flush_wgrad_finalize(c)) != VAE_OK) return rc;
             WgFinLayer& F = c.wg_fin.l[c.wg_fin.n++];
@@ -1217,6 +1249,9 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
         if (mid_inst == 1) MIDW_LAUNCH(1, 5, 4, 7);
         else MIDW_LAUNCH(2, 10, 5, 13);
 #undef MIDW_LAUNCH
+        VAE_TNAME("mid_wgrad_k<%d, %d, %d, %d, %s, %d>", wp.MT, wp.NT, mid_inst == 1 ? 4 : 5, mid_inst == 1 ? 7 : 13,
+                  !T ? "true" : "false", op.act == VAE_ACT_LEAKY ? 1 : 0);
+        VAE_TBYTES(4.0 * (double)c.B * ((double)g.Cin * g.H * g.W + 2.0 * g.Cout * g.OH * g.OW));
         VAE_LAUNCH_CHECK("mid_wgrad_k");
         if (c.wg_fin.n == WG_FIN_MAX_LAYERS && (rc = flush_wgrad_finalize(c)) != VAE_OK) return rc;
         WgFinLayer& L = c.wg_fin.l[c.wg_fin.n++];
@@ -1276,6 +1311,7 @@ static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
     }
     hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, rows, nrows, gamma, beta, save, rm, rv, C,
                        op.f[0], op.f[1], training, (float*)nullptr);
+    VAE_TBYTES(16.0 * C * (nrows + 1));
     VAE_LAUNCH_CHECK("bnv_finalize_fwd_k");
     c.last_blocks = 0;
     return VAE_OK;
@@ -1306,6 +1342,7 @@ static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
         hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(C), dim3(BNV_THREADS), 0, c.s, slab, nblocks, save, dgamma, dbeta, C,
                            n_local, (float*)nullptr, (const float*)nullptr);
     }
+    VAE_TBYTES(16.0 * C * (nblocks + 1));
     VAE_LAUNCH_CHECK("bnv_finalize_bwd_k");
     c.last_blocks = 0;
     return VAE_OK;
@@ -1334,6 +1371,8 @@ static int bn_forward(const Ctx& c, const vae_op& op, int training) {
         if (chunking(c.B, C, HW, &bchunk, &nchunks) != VAE_OK) return VAE_EINVAL;
         hipLaunchKernelGGL(chan_reduce_k<CR_STATS>, dim3(C, nchunks), dim3(256), 0, c.s, x, nullptr, nullptr, nullptr,
                            part, c.B, C, HW, bchunk, 0, 0.f, 0);
+        VAE_TNAME("chan_reduce_k<0>");
+        VAE_TBYTES(4.0 * (double)total);
         VAE_LAUNCH_CHECK("chan_reduce_k<STATS>");
         if (g_world > 1) {  // data-parallel: one {mean, -, M2, n} row per rank behind the partials, then a merge
             float* gath = resolve(c, op.r[9] + (int64_t)2 * C * VAE_MAX_CHUNKS, (int64_t)4 * C * g_world, "bn.rows", &ok);
@@ -1357,6 +1396,7 @@ static int bn_forward(const Ctx& c, const vae_op& op, int training) {
     }
     hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(total)), dim3(256), 0, c.s, x, y, save, gamma, beta, total, C, HW,
                        (op.flags & VAE_F_BN_RELU) ? 1 : 0);
+    VAE_TBYTES(8.0 * (double)total);
     VAE_LAUNCH_CHECK("bn_apply_k");
     return VAE_OK;
 }
@@ -1379,6 +1419,8 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
     if (chunking(c.B, C, HW, &bchunk, &nchunks) != VAE_OK) return VAE_EINVAL;
     hipLaunchKernelGGL(chan_reduce_k<CR_BNBWD>, dim3(C, nchunks), dim3(256), 0, c.s, x, dy, y, save, part, c.B, C, HW,
                        bchunk, 0, 0.f, (op.flags & VAE_F_BN_RELU) ? 1 : 0);
+    VAE_TNAME("chan_reduce_k<1>");
+    VAE_TBYTES(12.0 * (double)total);
     VAE_LAUNCH_CHECK("chan_reduce_k<BNBWD>");
     if (g_world > 1) {
         float* gath = resolve(c, op.r[9] + (int64_t)2 * C * VAE_MAX_CHUNKS, (int64_t)4 * C * g_world, "bn.rows", &ok);
@@ -1397,6 +1439,7 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
         VAE_LAUNCH_CHECK("bn_bwd_finalize_k");
     }
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(total)), dim3(256), 0, c.s, x, dy, dx, save, gamma, total, C, HW);
+    VAE_TBYTES(12.0 * (double)total);
     VAE_LAUNCH_CHECK("bn_bwd_apply_k");
     return VAE_OK;
 }
@@ -1434,6 +1477,8 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
         if (vec) hipLaunchKernelGGL((lin_fwd_k<true, false>), grid, dim3(LIN_THREADS), bytes, c.s, a);
         else hipLaunchKernelGGL((lin_fwd_k<false, false>), grid, dim3(LIN_THREADS), bytes, c.s, a);
     }
+    VAE_TNAME("lin_fwd_k<%s, %s>", vec ? "true" : "false", g_bf16 ? "true" : "false");
+    VAE_TBYTES(4.0 * ((double)a.B * ((double)a.K * a.nseg * (a.A2 != nullptr ? 2 : 1) + a.N + a.N2) + (double)a.K * a.nseg * (a.N + a.N2)));
     VAE_LAUNCH_CHECK(what);
     return VAE_OK;
 }
@@ -1468,6 +1513,13 @@ static int flush_linear_wgrads(const Ctx& c) {
     }
     if (g_bf16) hipLaunchKernelGGL(lin_wgrad_k<true>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
     else hipLaunchKernelGGL(lin_wgrad_k<false>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    if (vae_tl_timer != nullptr) {
+        double fl = 0;
+        for (int i = 0; i < m.n; ++i)
+            fl += (double)m.l[i].B * (m.l[i].K + (m.l[i].act != VAE_ACT_NONE ? 2.0 : 1.0) * m.l[i].N) + (double)m.l[i].gx * ((double)m.l[i].N * m.l[i].K + m.l[i].N);
+        VAE_TNAME("lin_wgrad_k<%s>", g_bf16 ? "true" : "false");
+        VAE_TBYTES(4.0 * fl);
+    }
     m.n = 0;
     VAE_LAUNCH_CHECK("lin_wgrad_k");
     return VAE_OK;
@@ -1603,6 +1655,7 @@ static int reparam_forward(const Ctx& c, const vae_op& op) {
     float* z = resolve(c, op.r[3], n, "reparam.z", &ok);
     if (!ok) return VAE_EINVAL;
     hipLaunchKernelGGL(reparam_fwd_k, dim3(ew_grid(n)), dim3(256), 0, c.s, mu, lv, eps, z, n);
+    VAE_TBYTES(16.0 * (double)n);
     VAE_LAUNCH_CHECK("reparam_fwd_k");
     return VAE_OK;
 }
@@ -1624,6 +1677,7 @@ static int reparam_backward(const Ctx& c, const vae_op& op) {
     if (!ok) return VAE_EINVAL;
     hipLaunchKernelGGL(reparam_bwd_k, dim3(ew_grid(n)), dim3(256), 0, c.s, mu, lv, eps, dz, gmu, glv, gs,
                        (op.flags & VAE_F_KL_GRAD) ? 1 : 0, dmu, dlv, n);
+    VAE_TBYTES(24.0 * (double)n);
     VAE_LAUNCH_CHECK("reparam_bwd_k");
     return VAE_OK;
 }
@@ -1772,6 +1826,18 @@ static int fc_launch(const Ctx& c, const FcChain& ch, const char* what) {
     const size_t bytes = (size_t)ch.lds_floats * sizeof(float);
     if (vec) hipLaunchKernelGGL(fc_chain_k<true>, grid, dim3(FC_THREADS), bytes, c.s, ch);
     else hipLaunchKernelGGL(fc_chain_k<false>, grid, dim3(FC_THREADS), bytes, c.s, ch);
+    if (vae_tl_timer != nullptr) {  // rows loaded and stored once per sample, every weight matrix once
+        double fl = 0;
+        for (int k = 0; k < ch.n; ++k) {
+            const FcStage& st = ch.st[k];
+            if (st.kind == FC_LOAD) fl += (double)c.B * st.N;
+            else if (st.kind == FC_GEMM) fl += (double)c.B * st.N * (st.has_mul ? 2 : 1) + (double)st.K * st.N * (st.W2 != nullptr ? 2 : 1);
+            else if (st.kind == FC_REPARAM_FWD) fl += 2.0 * c.B * st.N;
+            else fl += 5.0 * c.B * st.N;  // REPARAM_BWD: mu, logvar, eps in, two gradients out
+        }
+        VAE_TNAME("fc_chain_k<%s>", vec ? "true" : "false");
+        VAE_TBYTES(4.0 * fl);
+    }
     VAE_LAUNCH_CHECK(what);
     return VAE_OK;
 }
@@ -1906,6 +1972,7 @@ static int slice0_forward(const Ctx& c, const vae_op& op) {
     float* out = resolve(c, op.r[1], rows, "slice0.out", &ok);
     if (!ok) return VAE_EINVAL;
     hipLaunchKernelGGL(slice0_fwd_k, dim3(ew_grid(rows)), dim3(256), 0, c.s, in, out, rows, L);
+    VAE_TBYTES(8.0 * (double)rows);
     VAE_LAUNCH_CHECK("slice0_fwd_k");
     return VAE_OK;
 }
@@ -1917,6 +1984,7 @@ static int slice0_backward(const Ctx& c, const vae_op& op) {
     const float* dout = resolve(c, op.r[3], rows, "slice0.dout", &ok);
     if (!ok) return VAE_EINVAL;
     hipLaunchKernelGGL(slice0_bwd_k, dim3(ew_grid(rows * L)), dim3(256), 0, c.s, dout, din, rows * L, L);
+    VAE_TBYTES(4.0 * (double)rows * (L + 1));
     VAE_LAUNCH_CHECK("slice0_bwd_k");
     return VAE_OK;
 }
@@ -1926,6 +1994,7 @@ static int elbo_fwd_impl(hipStream_t s, const float* xr, const float* tg, const 
                          int accumulate, bool finalize = true) {
     hipLaunchKernelGGL(elbo_fwd_k, dim3(VAE_ELBO_BLOCKS), dim3(256), 0, s, xr, tg, mu, lv, partials, (int64_t)B, nps,
                        t_sb, t_se, latent, bce);
+    VAE_TBYTES(8.0 * (double)B * (nps + latent));
     VAE_LAUNCH_CHECK("elbo_fwd_k");
     if (!finalize) return VAE_OK;  // VAE_F_LOSS_IN_BWD: summed by the op's backward launch
     hipLaunchKernelGGL(elbo_finalize_k, dim3(1), dim3(256), 0, s, partials, out, VAE_ELBO_BLOCKS, accumulate);
@@ -1967,6 +2036,7 @@ static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullp
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid((int64_t)c.B * nps)), dim3(256), 0, c.s, xr, tg, nullptr, nullptr, gs,
                        dxr, nullptr, nullptr, (int64_t)c.B, nps, (int64_t)op.d[1], (int64_t)op.d[2], latent,
                        (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n, fin_part, fin_out, VAE_ELBO_BLOCKS, op.d[5]);
+    VAE_TBYTES(12.0 * (double)c.B * nps + 4.0 * (double)zero_n);
     VAE_LAUNCH_CHECK("elbo_bwd_k");
     return VAE_OK;
 }
@@ -2176,8 +2246,49 @@ extern "C" int vae_run_backward_step(const vae_op* ops, int n_ops, float* const*
     if (rc) return rc;
     hipLaunchKernelGGL(adam_step_k, dim3(ew_grid(base_sizes[1])), dim3(256), 0, c.s, bases[1], (const float*)bases[2], adam_m,
                        adam_v, base_sizes[1], 0.f, 0.f, 0.f, 0.f, tick, hyper, next_eps, next_eps_n, rng);
+    VAE_TBYTES(28.0 * (double)base_sizes[1] + 4.0 * (double)(next_eps != nullptr ? next_eps_n : 0));
     VAE_LAUNCH_CHECK("adam_step_k");
     return VAE_OK;
+}
+
+// Profiling twin of one whole train step: vae_run_forward (training) + vae_run_backward_step with a HIP event behind
+// EVERY kernel launch on the launch stream (VAE_LAUNCH_CHECK marks them while a timer is active on this thread).
+// Synchronises the stream; not capturable.
+extern "C" int vae_time_step(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes, int n_bases,
+                             int B, vae_stream_t stream, float* adam_m, float* adam_v, const float* hyper, int32_t* tick,
+                             float* ms, double* bytes, double* flops, char* names, int cap, int* n_launches) {
+    if (ms == nullptr || bytes == nullptr || flops == nullptr || names == nullptr || n_launches == nullptr || cap < 1 || cap > 4096)
+        VAE_FAIL(VAE_EINVAL, "time_step: bad arguments");
+    if (vae_tl_timer != nullptr) VAE_FAIL(VAE_EINVAL, "time_step: a timer is active already");
+    VaeTimer tm;
+    tm.s = (hipStream_t)stream; tm.n = 0; tm.cap = cap; tm.failed = false;
+    tm.ev = new hipEvent_t[cap + 1];
+    tm.names = reinterpret_cast<char (*)[VAE_TIMER_NAME]>(names);
+    tm.bytes = bytes; tm.flops = flops;
+    int made = 0, rc = VAE_OK;
+    for (; made <= cap; ++made)
+        if (hipEventCreate(&tm.ev[made]) != hipSuccess) break;
+    if (made <= cap) rc = VAE_EHIP, vae_set_error("time_step: hipEventCreate failed");
+    if (rc == VAE_OK && hipEventRecord(tm.ev[0], tm.s) != hipSuccess) rc = VAE_EHIP, vae_set_error("time_step: hipEventRecord failed");
+    if (rc == VAE_OK) {
+        vae_tl_timer = &tm;
+        rc = vae_run_forward(ops, n_ops, bases, base_sizes, n_bases, B, 1, stream);
+        if (rc == VAE_OK)
+            rc = hyper != nullptr ? vae_run_backward_step(ops, n_ops, bases, base_sizes, n_bases, B, stream, adam_m, adam_v, hyper,
+                                                          tick, nullptr, 0, nullptr)
+                                  : vae_run_backward(ops, n_ops, bases, base_sizes, n_bases, B, stream);
+        vae_tl_timer = nullptr;
+        vae_tl_bytes = vae_tl_flops = 0.0; vae_tl_name[0] = 0;
+    }
+    if (rc == VAE_OK && tm.failed) rc = VAE_EINVAL, vae_set_error("time_step: more than %d launches, or an event could not be recorded", cap);
+    if (rc == VAE_OK && hipEventSynchronize(tm.ev[tm.n]) != hipSuccess) rc = VAE_EHIP, vae_set_error("time_step: hipEventSynchronize failed");
+    for (int k = 0; k < tm.n && rc == VAE_OK; ++k)
+        if (hipEventElapsedTime(&ms[k], tm.ev[k], tm.ev[k + 1]) != hipSuccess) rc = VAE_EHIP, vae_set_error("hipEventElapsedTime failed");
+    if (rc == VAE_OK) *n_launches = tm.n;
+    else (void)hipStreamSynchronize(tm.s);  // nothing may still run against events that are about to be destroyed
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(tm.ev[i]);
+    delete[] tm.ev;
+    return rc;
 }
 
 extern "C" int64_t vae_seq_scratch_floats(const vae_op* ops, int n_ops, int B, int64_t nflat) {

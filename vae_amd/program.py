@@ -283,6 +283,17 @@ class CompiledProgram:
                                      ctypes.byref(n)), "vae_time_seq")
         return [(tags.raw[8 * k:8 * k + 8].split(b"\0")[0].decode(), ms[k], nbytes[k]) for k in range(n.value)]
 
+    def time_step(self, work, params, grads, state, ext, m=None, v=None, hyper=None, tick=None, stream=None, cap=256):
+        """One REAL train step (forward, backward, Adam when hyper is given) with a HIP event behind every launch on
+        the launch stream (vae_time_step); returns [(kernel name, device ms, algorithmic bytes, flops), ...]."""
+        self._bind(work, params, grads, state, ext)
+        ms, nbytes, flops = (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+        names, n = ctypes.create_string_buffer(64 * cap), ctypes.c_int32(0)
+        L.check(L.lib().vae_time_step(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
+                                      stream if stream is not None else L.stream_ptr(), L.ptr(m), L.ptr(v), L.ptr(hyper),
+                                      L.ptr(tick), ms, nbytes, flops, names, cap, ctypes.byref(n)), "vae_time_step")
+        return [(names.raw[64 * k:64 * k + 64].split(b"\0")[0].decode(), ms[k], nbytes[k], flops[k]) for k in range(n.value)]
+
     def backward(self, work, params, grads, state, ext, stream=None):
         self._bind(work, params, grads, state, ext)
         L.check(L.lib().vae_run_backward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
