@@ -112,6 +112,33 @@ def test_eval_forward(golden_case):
     close(loss, g["eval/loss"], atol=1e-2)
 
 
+@pytest.mark.parametrize("stem", ["tcvae_c3_n3_l60_fk21", "tcvae_c3_n4_l60_fk15", "multiscale_c3_l60"])
+def test_eval_pruned_decoder_equals_full_decoder(stem, monkeypatch):
+    """Eval forward of the 1-D families (train.py:75-89): by default the decoder is evaluated at time index 0 only
+    (Decoders.py:65 returns x[:, :, 0]) with every BatchNorm folded into the next layer's weights (seq1d.h, d.prune);
+    VAE_SEQ1D_PRUNE=0 runs the full decoder phases.  Both must give the golden eval outputs, at the golden batch and at a
+    ragged multi-chunk batch."""
+    g = load_golden(stem)
+    m = _build(stem)
+    m.load_state_dict(sub(g, "sd3/"))
+    m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(9)
+    xb = 50 + 10 * torch.randn(777, *g["x"].shape[1:], generator=gen)
+    eb = torch.randn(777, g["eps_eval"].shape[1], generator=gen)
+    outs = {}
+    for prune in ("1", "0"):
+        monkeypatch.setenv("VAE_SEQ1D_PRUNE", prune)
+        with torch.no_grad():
+            x_rec, mu, logvar = m(g["x"].to(DEV), eps=g["eps_eval"].to(DEV))
+            big = m(xb.to(DEV), eps=eb.to(DEV))
+        close(x_rec, g["eval/x_rec"])
+        close(mu, g["eval/mu"])
+        close(logvar, g["eval/logvar"])
+        outs[prune] = [t.clone() for t in big]
+    for a, b in zip(outs["1"], outs["0"]):
+        close(a, b.cpu(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("stem,family,kw,B", [
     ("mnist_lat15", "mnist", {}, 300),
     ("multiscale_c3_l60", "multiscale", {}, 517),

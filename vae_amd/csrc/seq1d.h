@@ -66,6 +66,7 @@ struct SqHead {
 };
 struct SqDesc {
     int B, SB, grid, nchunks, training;
+    int prune;       // eval forward without a criterion: the decoder is evaluated at time index 0 only (sq_fh_k)
     int NE, ND, nenc, lat, lat_total;
     int C, L;        // input window (C, L)
     float slope;     // LeakyReLU slope of every conv / convT (0 = ReLU)
@@ -756,6 +757,35 @@ __device__ __forceinline__ void sq_zero(float* p, int n) {
     for (int e = threadIdx.x; e < n; e += SQ_THREADS) p[e] = 0.f;
 }
 
+// ---- eval mode: BatchNorm folded into the consumer's weights ---------------------------------------------------
+// With running statistics a BatchNorm is the per-channel affine map v -> v*sc + t (sc = gamma*rstd, t = beta - mean*sc),
+// and in the 1-D models the layer behind it is linear in that value and has no padding (Conv -> LeakyReLU -> BatchNorm
+// -> next Conv / Linear: Encoders.py:42-48, 84-85; multiscale_vae.py:54-63), so the map moves into the consumer's LDS
+// copy of its weights once per launch: W[n][q] *= sc[c(q)], bias[n] += sum_q t[c(q)] * W[n][q] with c(q) = q / per.
+// The coefficient block then becomes the identity and the staging code passes the stored activations through.
+// W: rows [N][K] in LDS, complete, like bias [N] and coef (mean, rstd, scale, shift; C channels).  Ends with a barrier.
+__device__ __forceinline__ void sq_fold_bn_rows(float* W, float* bias, float* coef, int N, int K, int per, int C) {
+    const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    for (int n0 = 0; n0 < N; n0 += SQ_THREADS / 16) {  // 16 lanes per output row
+        const int n = n0 + grp;
+        float a = 0.f;
+        if (n < N)
+            for (int q = l16; q < K; q += 16) {
+                const int c = q / per;
+                a = fmaf(coef[3 * C + c] - coef[c] * coef[2 * C + c], W[n * K + q], a);
+            }
+        a = sq_row_sum(a);
+        if (n < N && l16 == 0) bias[n] += a;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (generic pointers: flat accesses)
+    for (int e = threadIdx.x; e < N * K; e += SQ_THREADS) W[e] *= coef[2 * C + (e % K) / per];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int c = threadIdx.x; c < C; c += SQ_THREADS) {
+        coef[c] = 0.f; coef[C + c] = 1.f; coef[2 * C + c] = 1.f; coef[3 * C + c] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Sum of v over the workgroup, valid in thread 0 (red: >= SQ_WAVES floats of LDS; fixed order)
 __device__ __forceinline__ float sq_block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -848,6 +878,11 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fe_k(SqDesc d, int i) {
         sq_zero(wst[e], 3 * y.cout);
     }
     sq_bar_dma();
+    if (!d.training && i > 0)  // eval: BatchNorm_{i-1} (running statistics) folded into this layer's weights
+        _Pragma("unroll") for (int e = 0; e < NENC; ++e) {
+            const SqLayer& y = d.enc[e][i];
+            sq_fold_bn_rows(W[e], Bi[e], coef[e], y.cout, y.cin * y.k, y.k, y.cin);
+        }
     SQ_T(1);
     for (;;) {
         const int s0 = chunk * d.SB, sb = min(d.SB, d.B - s0);
@@ -912,6 +947,14 @@ __host__ __device__ inline int sq_lds_fh(const SqDesc& d, int SB) {
     l.take(y0.cin * d.lat_total); l.take(y0.cin); l.take(SQ_KT(d.lat_total));
     l.take(y0.cin * y0.cout * 2); l.take(y0.cout); l.take(SQ_KT(y0.cin));
     l.take(SB * y0.cin); l.take(SB * y0.cout * y0.lout); l.take(3 * y0.cout); l.take(16);
+    // eval (d.prune): the decoder at time index 0 only: per layer the folded tap-0 weights [cin][cout] and bias, and two
+    // [SB][channels] vectors (always reserved: the chunk plan does not depend on the mode)
+    int cmax = 1;
+    for (int j = 0; j < d.ND; ++j) {
+        l.take(d.dec[j].cin * d.dec[j].cout); l.take(d.dec[j].cout);
+        if (d.dec[j].cout > cmax) cmax = d.dec[j].cout;
+    }
+    l.take(SB * cmax); l.take(SB * cmax);
     return l.off;
 }
 template <int NENC>
@@ -956,6 +999,45 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fh_k(SqDesc d) {
     float* OUT = smem + l.take(d.SB * y0.cout * y0.lout);
     float* wst = smem + l.take(3 * y0.cout);
     float* red = smem + l.take(16);
+    // (the pruned decoder's region is walked with a running offset: an array of pointers indexed by the run-time layer
+    // number would live in scratch memory)
+    const int pr_base = l.off;
+    int cmax = 1;
+    for (int j = 0; j < d.ND; ++j) {
+        l.take(d.dec[j].cin * d.dec[j].cout); l.take(d.dec[j].cout);
+        cmax = max(cmax, d.dec[j].cout);
+    }
+    float* const PV0 = smem + l.take(d.SB * cmax);
+    float* const PV1 = smem + l.take(d.SB * cmax);
+    if (d.prune) {
+        // Eval: x_rec = x[:, :, 0] of the last layer (Decoders.py:65; multiscale_vae.py:192), and position 0 of a
+        // ConvTranspose1d(k 2, s 2) output depends only on position 0 of its input through tap 0: the decoder behind
+        // the Linear layer is a chain of [cin x cout] products per sample.  BatchNorm_{j-1} (running statistics, behind
+        // the activation) is folded into layer j: WF_j[ci][co] = sc[ci] * w_j[ci][co][0], bF_j[co] = b_j[co] + sum_ci
+        // t[ci] * w_j[ci][co][0].
+        SqLds lp = {pr_base};
+        for (int j = 0; j < d.ND; ++j) {
+            const SqLayer& y = d.dec[j];
+            const SqLayer& pb = d.dec[j > 0 ? j - 1 : 0];
+            float* const WFj = smem + lp.take(y.cin * y.cout);
+            float* const bFj = smem + lp.take(y.cout);
+            for (int e = threadIdx.x; e < y.cin * y.cout; e += SQ_THREADS) {
+                const int ci = e / y.cout;
+                float sc = 1.f;
+                if (j > 0) sc = pb.gamma[ci] * rsqrtf(pb.rvar[ci] + pb.bn_eps);
+                WFj[e] = sc * y.w[2 * e];
+            }
+            for (int co = threadIdx.x; co < y.cout; co += SQ_THREADS) {
+                float a = y.b[co];
+                if (j > 0)
+                    for (int ci = 0; ci < y.cin; ++ci) {
+                        const float sc = pb.gamma[ci] * rsqrtf(pb.rvar[ci] + pb.bn_eps);
+                        a = fmaf(pb.beta[ci] - pb.rmean[ci] * sc, y.w[2 * (ci * y.cout + co)], a);
+                    }
+                bFj[co] = a;
+            }
+        }
+    }
     sq_dma_in(Wl, d.wl, y0.cin * d.lat_total); sq_dma_in(bl, d.bl, y0.cin);
     sq_dma_in(W0, y0.w, y0.cin * y0.cout * 2); sq_dma_in(b0, y0.b, y0.cout);
     if (NENC == 2) sq_bn_prepare2(d.enc[0][d.NE - 1], coef[0], d.enc[NENC - 1][d.NE - 1], coef[NENC - 1], d.training);
@@ -965,6 +1047,11 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fh_k(SqDesc d) {
     sq_ktab(kt0, sq_ix(y0.cin, 1, y0.lin, 0, 2 * y0.cout, 0));
     sq_zero(wst, 3 * y0.cout);
     sq_bar_dma();
+    if (!d.training)  // eval: the encoders' last BatchNorm folded into the mu / logvar heads
+        _Pragma("unroll") for (int e = 0; e < NENC; ++e) {
+            const SqLayer& p = d.enc[e][d.NE - 1];
+            sq_fold_bn_rows(WH[e], bh[e], coef[e], 2 * d.lat, d.head[e].K, p.lout, p.cout);
+        }
     SQ_T(1);
     const int lvd = (int)(LV - MU);
     float kl = 0.f, rec = 0.f;
@@ -999,12 +1086,33 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fh_k(SqDesc d) {
         sq_bar();
         SQ_T(5);
         sq_copy_out(d.h0 + (int64_t)s0 * y0.cin, H0, sb * y0.cin);
+        if (d.prune) {  // the decoder at time index 0, one (sample, channel) value per thread and layer
+            const float* cur = H0;
+            SqLds lp = {pr_base};
+            for (int j = 0; j < d.ND; ++j) {
+                const SqLayer& y = d.dec[j];
+                const float* const WFj = smem + lp.take(y.cin * y.cout);
+                const float* const bFj = smem + lp.take(y.cout);
+                float* nxt = (j & 1) ? PV1 : PV0;
+                for (int e = threadIdx.x; e < sb * y.cout; e += SQ_THREADS) {
+                    const int sidx = e / y.cout, co = e - sidx * y.cout;
+                    float a = bFj[co];
+                    for (int ci = 0; ci < y.cin; ++ci) a = fmaf(cur[sidx * y.cin + ci], WFj[ci * y.cout + co], a);
+                    a = a > 0.f ? a : a * d.slope;
+                    nxt[e] = a;
+                    if (j == d.ND - 1) d.xrec[(int64_t)s0 * y.cout + e] = a;
+                }
+                cur = nxt;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        } else {
         sq_convT_fwd(y0, sb, kt0, H0, W0, b0, OUT, d.slope);
         sq_bar();
         SQ_T(6);
         sq_copy_out(y0.y + (int64_t)s0 * y0.cout * y0.lout, OUT, sb * y0.cout * y0.lout);
         if (d.ND == 1) rec += sq_xrec_out(d, y0, OUT, s0, sb);
         if (d.training && y0.has_bn) sq_tile_stats(OUT, sb, y0.cout, y0.lout, wst);
+        }
         chunk += gridDim.x;
         if (chunk >= d.nchunks) break;
         sq_bar();

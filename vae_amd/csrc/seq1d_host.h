@@ -279,6 +279,8 @@ static int sq_bind(const Ctx& c, const vae_op* ops, SqProgram* p, int training, 
             d.efin = 1; d.eacc = eo.d[5];
         }
     }
+    // eval forward without a criterion: the decoder is evaluated at time index 0 only, inside the heads phase (f3)
+    d.prune = (!training && !backward && !d.has_elbo && sq_env_int("VAE_SEQ1D_PRUNE", 1) != 0) ? 1 : 0;
     if (backward) {
         d.dxrec = resolve(c, sl.r[3], (int64_t)B * d.dec[d.ND - 1].cout, "seq1d.dx_rec", &ok);
         if (rp.flags & VAE_F_EXT_GRAD) {
@@ -377,7 +379,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
     if (d.nenc == 1) hipLaunchKernelGGL(sq_fh_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     else hipLaunchKernelGGL(sq_fh_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     VAE_LAUNCH_CHECK("sq_fh_k");
-    for (int j = 1; j < d.ND; ++j) {
+    for (int j = 1; j < d.ND && !d.prune; ++j) {
         const SqLayer& y = d.dec[j];
         double fl = Bd * ((double)y.cin * y.lin + (double)y.cout * y.lout) + sq_layer_w(y);
         if (j == d.ND - 1) fl = Bd * ((double)y.cin * y.lin + (d.has_elbo ? 3.0 : 1.0) * y.cout) + sq_layer_w(y);  // only x[:, :, 0] leaves
