@@ -69,7 +69,15 @@ enum {
     VAE_F_LOSS_IN_BWD = 128, /* ELBO: forward leaves the per-workgroup partials; the fixed-order sum into out[0..3]
                               is done by the op's backward launch (a train step always runs it: one launch less).
                               No counterpart in the reference (train.py:39-48 computes the loss eagerly). */
+    VAE_F_BN_ACC = 256,    /* BN (VAE_F_FUSED): the save block r[6] is followed by VAE_BN_ACC_FLOATS(C) floats of
+                              fixed-point accumulators (the producers' per-channel sums, added with 64-bit integer
+                              atomics), and the save blocks of all such BN ops of a program lie back to back (each padded
+                              to a multiple of 64 floats) so that one memset at the start of a training forward clears
+                              them.  The BatchNorm is then finalised in the prologue of its first consumer kernel
+                              instead of a launch of its own.  CONV/CONVT (VAE_F_FUSED): the blocks r[7] / r[8] name
+                              are such blocks.  Single GPU only (under vae_set_collective the rows are gathered). */
 };
+#define VAE_BN_ACC_FLOATS(C) (1536 * (C))  /* 2 directions x 3 quantities x 16 shards x C channels x a 64-byte line each, in floats */
 
 /* One program op.  Field use per kind ("-" unused):
  *  CONV/CONVT r: 0 in, 1 out, 2 din(-1: none), 3 dout, 4 w, 5 b (w,b: PARAM refs), 6 partials (WORK,
@@ -119,7 +127,10 @@ int vae_check_device(void);
 
 /* Executes ops[0..n) forward / backward for a batch of B samples.
  * bases[i] / base_sizes[i] (floats) describe the address spaces; training != 0 selects
- * BatchNorm batch statistics + running-stat update. */
+ * BatchNorm batch statistics + running-stat update.  training == 1 also clears the BatchNorm accumulator blocks
+ * (VAE_F_BN_ACC) first; training == 2 skips that: the caller vouches that they are zero (a zeroed workspace, or the
+ * previous pass over this workspace was a vae_run_backward* that began with the program's ELBO op, which clears them
+ * on the way: the fused train step). */
 int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,
                     int n_bases, int B, int training, vae_stream_t stream);
 int vae_run_backward(const vae_op* ops, int n_ops, float* const* bases, const int64_t* base_sizes,

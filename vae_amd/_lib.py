@@ -16,6 +16,12 @@ OP_CONV, OP_CONVT, OP_BN, OP_LINEAR, OP_REPARAM, OP_SLICE0, OP_ELBO = 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
 F_ACC_DIN, F_BN_RELU, F_KL_GRAD, F_EXT_GRAD, F_BCE, F_IN_RELU, F_FUSED = 1, 2, 4, 8, 16, 32, 64
 F_LOSS_IN_BWD = 128
+F_BN_ACC = 256
+BN_ACC_MAXC = 16  # igemm.h BNFIN_MAXC
+
+
+def bn_acc_floats(C):
+    return 1536 * C  # include/vae_amd.h VAE_BN_ACC_FLOATS
 DP_ID_BYTES = 256  # include/vae_amd.h: VAE_DP_ID_BYTES
 MAX_CHUNKS, ELBO_BLOCKS, MAX_WORLD = 64, 1024, 64
 SP_WORK, SP_PARAM, SP_GRAD, SP_STATE, SP_EXT0 = 0, 1, 2, 3, 4

@@ -119,6 +119,13 @@ __global__ __launch_bounds__(256) void elbo_finalize_k(const float* __restrict__
 }
 
 // d(loss)/d(x_rec) (and optionally the KL grads when dmu != nullptr), scaled by gscale[0]
+// extra ranges the first kernel of a backward pass clears on its way (the BatchNorm accumulators: igemm.h BnFin)
+#define ZERO_RANGES_MAX 8
+struct ZeroRanges {
+    float* p[ZERO_RANGES_MAX];
+    int64_t n[ZERO_RANGES_MAX];
+    int cnt;
+};
 __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, const float* __restrict__ tg,
                                                   const float* __restrict__ mu, const float* __restrict__ lv,
                                                   const float* __restrict__ gscale, float* __restrict__ dxr,
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
                                                   float* __restrict__ zero_buf, int64_t zero_n,
                                                   const float* __restrict__ fin_partials = nullptr,
                                                   float* __restrict__ fin_out = nullptr, int fin_blocks = 0,
-                                                  int fin_accumulate = 0) {
+                                                  int fin_accumulate = 0, ZeroRanges zr = ZeroRanges{}) {
     // fin_partials: the forward left the fixed-order sum of its partials to this launch (VAE_F_LOSS_IN_BWD: one graph
     // node less per train step); workgroup 0 does what elbo_finalize_k does
     if (fin_partials != nullptr && blockIdx.x == 0) {
@@ -152,6 +159,10 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
     // the first kernel of a backward pass also clears the flat gradient buffer (a memset node of its own costs a
     // launch: 4.6 us of a step that is bound by them)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero_buf[i] = 0.f;
+    // ... and the BatchNorm accumulators (igemm.h BnFin): this step's backward sums start from zero, and so do the next
+    // step's forward statistics (a fused train step then needs no memset node at all)
+    for (int q = 0; q < zr.cnt; ++q)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zr.n[q]; i += stride) zr.p[q][i] = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += stride) {
         int64_t ti = i;
         if (!(t_se == 1 && t_sb == nps)) {

@@ -73,6 +73,153 @@ struct FastDiv {  // exact n / d for n * d < 2^32
 };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d == 1 ? n : __umulhi(n, f.mul); }
 
+// ---- a virtual BatchNorm finalised inside its first consumer's prologue ---------------------------------------
+// A finalize launch of its own (bnv_finalize_*_k) costs 4.6-6.5 us plus a kernel boundary on KB-sized data, six times
+// per MNIST step.  Merging the producers' per-workgroup rows in every consumer workgroup's prologue was measured and
+// lost (512 rows x 16 channels per workgroup: +4..13 us per consumer, 0.521 -> 0.545 ms/step).  What is built: besides
+// its row, every producer workgroup adds its per-channel sums to FIXED-POINT 64-bit accumulators with integer atomics
+// (integer addition is associative: the totals are bit-identical from run to run whatever the arrival order, unlike
+// float atomics), sharded sixteen ways by blockIdx.x & 15, every word in a 64-byte line of its own (atomics execute at
+// the memory side, one line at a time: with the three words of a channel in one line and eight shards the producers'
+// tails grew by 2-4 us).  The first consumer kernel then reads 16 x 3 words per channel in its prologue (requested at
+// the top of the kernel, used after its set-up; every workgroup the same words, so all hold bit-identical coefficients) and workgroup 0 stores the save block, the running
+// statistics (forward) or dgamma / dbeta (backward) for the kernels that follow.  The accumulators live right behind
+// the BatchNorm's save block (8*C floats): [fwd | bwd][quantity 3][shard 16][C][line of 8 words]; the host zeroes them at the
+// start of every training-mode forward pass (one memset for all BatchNorms of a program).
+//   forward : word 0 = n, 1 = sum n_w*(mean_w - p) * 2^24, 2 = sum (M2_w + n_w*(mean_w - p)^2) * 2^24, with the pivot
+//             p = the BatchNorm's running mean before this step (producer workgroup 0 leaves it in save[7*C + c])
+//   backward: word 0 = sum g * 2^32, 1 = sum g*xhat * 2^32
+// Ranges: |sum| < 2^63 / scale = 5.5e11 (forward: n * (var + (mean - p)^2)) and 2.1e9 (backward sums).
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    const float tot = n + nb;
+    if (tot > 0.f) {
+        const float delta = mb - mean;
+        const float f = nb / tot;
+        mean = fmaf(delta, f, mean);
+        m2 += m2b + delta * delta * n * f;
+    }
+    n = tot;
+}
+#define BNACC_SHARDS 16
+#define BNACC_NW 3     // quantities per (shard, channel)
+#define BNACC_LINE 8   // 8-byte words per 64-byte line: every (quantity, shard, channel) word has a line of its own
+#define BNACC_DIR_WORDS(C) (BNACC_NW * BNACC_SHARDS * (C) * BNACC_LINE)
+#define BNACC_FLOATS(C) (2 * BNACC_DIR_WORDS(C) * 2)  // forward + backward accumulators, in floats
+#define BNACC_FWD_SCALE 16777216.0    // 2^24
+#define BNACC_BWD_SCALE 4294967296.0  // 2^32
+typedef unsigned long long bnacc_t;
+__device__ __forceinline__ bnacc_t* bnacc_fwd(const float* save, int C) {
+    return reinterpret_cast<bnacc_t*>(const_cast<float*>(save) + 8 * C);
+}
+__device__ __forceinline__ bnacc_t* bnacc_bwd(const float* save, int C) { return bnacc_fwd(save, C) + BNACC_DIR_WORDS(C); }
+__device__ __forceinline__ int bnacc_idx(int C, int word, int shard, int c) { return ((word * BNACC_SHARDS + shard) * C + c) * BNACC_LINE; }
+// one producer workgroup's (n, mean, M2) of channel c (called by one lane per channel)
+__device__ __forceinline__ void bnacc_add_fwd(const float* save, int C, int c, float n, float mean, float m2, float pivot) {
+    bnacc_t* p = bnacc_fwd(save, C);
+    const int sh = blockIdx.x & (BNACC_SHARDS - 1);
+    const double dm = (double)mean - (double)pivot, dn = (double)n;
+    atomicAdd(p + bnacc_idx(C, 0, sh, c), (bnacc_t)(long long)n);
+    atomicAdd(p + bnacc_idx(C, 1, sh, c), (bnacc_t)__double2ll_rn(dn * dm * BNACC_FWD_SCALE));
+    atomicAdd(p + bnacc_idx(C, 2, sh, c), (bnacc_t)__double2ll_rn(((double)m2 + dn * dm * dm) * BNACC_FWD_SCALE));
+}
+__device__ __forceinline__ void bnacc_add_bwd(const float* save, int C, int c, float s1, float s2) {
+    bnacc_t* p = bnacc_bwd(save, C);
+    const int sh = blockIdx.x & (BNACC_SHARDS - 1);
+    atomicAdd(p + bnacc_idx(C, 0, sh, c), (bnacc_t)__double2ll_rn((double)s1 * BNACC_BWD_SCALE));
+    atomicAdd(p + bnacc_idx(C, 1, sh, c), (bnacc_t)__double2ll_rn((double)s2 * BNACC_BWD_SCALE));
+}
+struct BnFin {
+    const float* slab;  // the producers' rows [nrows][C][4]: only the host's fallback (bn_flush_pending) reads them
+    int nrows, C, training;
+    const float* gamma;
+    const float* beta;
+    float* save;     // [8*C]: mean, rstd, scale, beta, a, b, c, pivot; the accumulators follow
+    float* rmean;    // forward: running statistics
+    float* rvar;
+    float* dgamma;   // backward
+    float* dbeta;
+    float eps, momentum, n_local;
+};
+#define BNFIN_MAXC 16
+#define BNFIN_SCR_FLOATS (BNACC_NW * BNACC_SHARDS * BNFIN_MAXC * 2)  // LDS scratch of a finalize prologue (8-byte aligned)
+// The consumer's prologue in two parts: bnfin_issue at the very top of the kernel (thread t < 16*C requests the three
+// words of (shard t / C, channel t % C); nothing waits on them), bnfin_forward / bnfin_backward after the kernel's
+// own set-up, where their latency has passed.
+struct BnFinRegs {
+    long long a0, a1, a2;
+};
+template <bool BWD>
+__device__ __forceinline__ void bnfin_issue(const BnFin& f, BnFinRegs& r) {
+    r.a0 = r.a1 = r.a2 = 0;
+    const int C = f.C, tid = threadIdx.x;
+    if (C > 0 && f.training && tid < BNACC_SHARDS * C) {
+        const long long* p = reinterpret_cast<const long long*>(BWD ? bnacc_bwd(f.save, C) : bnacc_fwd(f.save, C));
+        const int sh = tid / C, c = tid - sh * C;
+        r.a0 = p[bnacc_idx(C, 0, sh, c)];
+        r.a1 = p[bnacc_idx(C, 1, sh, c)];
+        if (!BWD) r.a2 = p[bnacc_idx(C, 2, sh, c)];
+    }
+}
+// coef (LDS): [0,C) mean, [C,2C) rstd, [2C,3C) scale, [3C,4C) beta.  scr (LDS): BNFIN_SCR_FLOATS.  All T >= 16*C
+// threads call; ends with a workgroup barrier.
+template <int T>
+__device__ __forceinline__ void bnfin_forward(const BnFin& f, const BnFinRegs& r, float* coef, float* scr) {
+    static_assert(T >= BNACC_SHARDS * BNFIN_MAXC, "one thread per (shard, channel)");
+    const int C = f.C, tid = threadIdx.x;
+    long long* w = reinterpret_cast<long long*>(scr);
+    if (f.training) {
+        if (tid < BNACC_SHARDS * C) { w[3 * tid] = r.a0; w[3 * tid + 1] = r.a1; w[3 * tid + 2] = r.a2; }
+        __syncthreads();
+        if (tid < C) {
+            long long s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < BNACC_SHARDS; ++k) { s0 += w[3 * (k * C + tid)]; s1 += w[3 * (k * C + tid) + 1]; s2 += w[3 * (k * C + tid) + 2]; }
+            const double n = (double)s0, d1 = (double)s1 / BNACC_FWD_SCALE, d2 = (double)s2 / BNACC_FWD_SCALE;
+            const double dmean = d1 / n;
+            const float mean = (float)((double)f.save[7 * C + tid] + dmean);
+            const float var = (float)(fmax(d2 - d1 * dmean, 0.0) / n);
+            const float rstd = rsqrtf(var + f.eps), sc = f.gamma[tid] * rstd, be = f.beta[tid];
+            coef[tid] = mean; coef[C + tid] = rstd; coef[2 * C + tid] = sc; coef[3 * C + tid] = be;
+            if (blockIdx.x == 0) {
+                f.save[tid] = mean; f.save[C + tid] = rstd; f.save[2 * C + tid] = sc; f.save[3 * C + tid] = be;
+                const float nf = (float)n, unbiased = nf > 1.f ? var * nf / (nf - 1.f) : var;
+                f.rmean[tid] = (1.f - f.momentum) * f.rmean[tid] + f.momentum * mean;
+                f.rvar[tid] = (1.f - f.momentum) * f.rvar[tid] + f.momentum * unbiased;
+            }
+        }
+    } else if (tid < C) {  // eval: running statistics
+        const float mean = f.rmean[tid], rstd = rsqrtf(f.rvar[tid] + f.eps), sc = f.gamma[tid] * rstd, be = f.beta[tid];
+        coef[tid] = mean; coef[C + tid] = rstd; coef[2 * C + tid] = sc; coef[3 * C + tid] = be;
+        if (blockIdx.x == 0) { f.save[tid] = mean; f.save[C + tid] = rstd; f.save[2 * C + tid] = sc; f.save[3 * C + tid] = be; }
+    }
+    __syncthreads();
+}
+// cgr (LDS): [0,C) mean, [C,2C) a, [2C,3C) b, [3C,4C) c of the gradient transform g' = a*g + b*(y - mean) + c.
+template <int T>
+__device__ __forceinline__ void bnfin_backward(const BnFin& f, const BnFinRegs& r, float* cgr, float* scr) {
+    static_assert(T >= BNACC_SHARDS * BNFIN_MAXC, "one thread per (shard, channel)");
+    const int C = f.C, tid = threadIdx.x;
+    long long* w = reinterpret_cast<long long*>(scr);
+    if (tid < BNACC_SHARDS * C) { w[2 * tid] = r.a0; w[2 * tid + 1] = r.a1; }
+    __syncthreads();
+    if (tid < C) {
+        long long t1 = 0, t2 = 0;
+#pragma unroll
+        for (int k = 0; k < BNACC_SHARDS; ++k) { t1 += w[2 * (k * C + tid)]; t2 += w[2 * (k * C + tid) + 1]; }
+        const float s1 = (float)((double)t1 / BNACC_BWD_SCALE), s2 = (float)((double)t2 / BNACC_BWD_SCALE);
+        const float m1 = s1 / f.n_local, m2 = s2 / f.n_local;
+        const float mean = f.save[tid], rstd = f.save[C + tid], sc = f.save[2 * C + tid];
+        const float ga = sc, gb = -sc * m2 * rstd, gc = -sc * m1;
+        cgr[tid] = mean; cgr[C + tid] = ga; cgr[2 * C + tid] = gb; cgr[3 * C + tid] = gc;
+        if (blockIdx.x == 0) {
+            f.dbeta[tid] = s1;
+            f.dgamma[tid] = s2;
+            f.save[4 * C + tid] = ga; f.save[5 * C + tid] = gb; f.save[6 * C + tid] = gc;
+        }
+    }
+    __syncthreads();
+}
+
 struct IgGeom {
     int Cin, H, W;      // gathered tensor, per sample
     int N, OH, OW;      // produced tensor
@@ -118,6 +265,11 @@ struct IgArgs {
     int pre;  // 1: chunks fit the register prefetch (<= IG_PRE*IG_THREADS input elements)
     FastDiv d_N, d_ntile;  // by N and by Np/16
     IgClass cls[4];
+    BnFin fin;  // forward, in.mode == TR_BN: the producer BatchNorm is finalised in this kernel's prologue (C > 0)
+    // the sums that go to `slab` are also added to the fixed-point accumulators behind this save block (nullptr: no):
+    // forward statistics of the BatchNorm that follows (pivot: its running mean), or EP_BNGRAD's backward sums
+    float* acc_save;
+    const float* acc_pivot;
 };
 
 #ifdef IG_TIMERS  // diagnostic build only: phase stamps of workgroup 1 (wall clock, 10 ns ticks)
@@ -267,6 +419,8 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
     // the first chunk's loads are issued before anything else: the set-up below hides their latency
     const int CHW = g.Cin * g.H * g.W;
+    BnFinRegs finr;
+    bnfin_issue<false>(a.fin, finr);  // the producer BatchNorm's accumulators (finalised below, behind the tables)
     PreRegs<IG_PRE, GRAD> pr;
     if (a.pre) {
         pre_decode(pr, (uint32_t)(a.SB * CHW), g.Cin, g.H * g.W, g.W, g.Hp, g.Wp, g.halo_h, g.halo_w, g.d_CHW, g.d_HW,
@@ -279,6 +433,12 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // build the pixel table, the tap-offset tables and the [k][n] weight images of every class
     float* const dummy = lbias + g.Np;  // spare LDS word: masked-off epilogue stores land here
     int* const wbase = reinterpret_cast<int*>(lbias + g.Np + 8);  // [lds_tab] weight base index per reduction row (set-up only)
+    // [4*Np] this workgroup's running per-channel sums over its chunks (one slab row per WORKGROUP, written at the end)
+    float* const wstat = reinterpret_cast<float*>(wbase + a.lds_tab);
+    for (int i = tid; i < 4 * g.Np; i += IG_THREADS) wstat[i] = 0.f;
+    // the producer's BatchNorm finalised here (every workgroup merges the producer's rows; lout is free until the first
+    // tiles): behind the first chunk's loads, before the tables
+    const float* const cin_src = a.fin.C > 0 ? nullptr : a.in.coef;
     if (a.ncls > 1) {
 #define MULTI 1
 #include "igemm_tables.inc"
@@ -288,6 +448,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #include "igemm_tables.inc"
 #undef MULTI
     }
+    if (a.fin.C > 0) bnfin_forward<IG_THREADS>(a.fin, finr, cin, lout);  // (lout is free until the first tiles)
 
     // Chunk loop, two LDS-only barriers per round:
     //   [barrier] issue the loads of chunk c+1 | MFMA tiles of chunk c (lin -> lout)
@@ -507,12 +668,11 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
-                if (lane == 0) {
-                    float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
-                    sl[0] = pv;
-                    sl[1] = s1;
-                    sl[2] = s2;
-                    sl[3] = (float)(sb * OHW);
+                if (lane == 0) {  // Chan-merge this chunk into the workgroup's running (n, mean, M2) of the channel
+                    const float cn = (float)(sb * OHW), dd = s1 / cn;
+                    float rn = wstat[4 * n], rmean = wstat[4 * n + 1], rm2 = wstat[4 * n + 2];
+                    chan_merge(rn, rmean, rm2, cn, pv + dd, fmaxf(s2 - s1 * dd, 0.f));
+                    wstat[4 * n] = rn; wstat[4 * n + 1] = rmean; wstat[4 * n + 2] = rm2;
                 }
             }
             continue;
@@ -548,13 +708,28 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
                 if (lane == 0) {
-                    float* sl = a.slab + ((int64_t)chunk * g.N + n) * 4;
-                    sl[0] = s1;
-                    sl[1] = s2;
+                    wstat[4 * n] += s1;
+                    wstat[4 * n + 1] += s2;
                 }
             }
         }
     }
+    // one slab row per workgroup (channel n belongs to wave n % IG_WAVES all along: no barrier needed)
+    if (a.slab != nullptr && lane == 0)
+        for (int n = wid; n < g.N; n += IG_WAVES) {
+            float4* sl = reinterpret_cast<float4*>(a.slab + ((int64_t)blockIdx.x * g.N + n) * 4);
+            if (a.ep_mode == EP_PLAIN) {
+                *sl = make_float4(wstat[4 * n + 1], 0.f, wstat[4 * n + 2], wstat[4 * n]);  // {pivot = mean, 0, M2, n}
+                if (a.acc_save != nullptr) {
+                    const float pv = a.acc_pivot[n];
+                    bnacc_add_fwd(a.acc_save, g.N, n, wstat[4 * n], wstat[4 * n + 1], wstat[4 * n + 2], pv);
+                    if (blockIdx.x == 0) a.acc_save[7 * g.N + n] = pv;
+                }
+            } else {
+                *sl = make_float4(wstat[4 * n], wstat[4 * n + 1], 0.f, 0.f);
+                if (a.acc_save != nullptr) bnacc_add_bwd(a.acc_save, g.N, n, wstat[4 * n], wstat[4 * n + 1]);
+            }
+        }
     IG_T();
 #ifdef IG_TIMERS
     if (threadIdx.x == 0 && blockIdx.x == 1)
@@ -864,16 +1039,6 @@ __global__ __launch_bounds__(256) void wgrad_finalize_k(WgFinMulti m) {
 // turned into (n, mean, M2) and merged with Chan's parallel-variance formula, lanes first striding
 // over the blocks and then in a fixed butterfly, so the result is deterministic and does not lose
 // precision when |mean| >> std.  Writes save = {mean, rstd, scale, beta} and the running stats.
-__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-    const float tot = n + nb;
-    if (tot > 0.f) {
-        const float delta = mb - mean;
-        const float f = nb / tot;
-        mean = fmaf(delta, f, mean);
-        m2 += m2b + delta * delta * n * f;
-    }
-    n = tot;
-}
 #define BNV_THREADS 256
 __global__ __launch_bounds__(BNV_THREADS) void bnv_finalize_fwd_k(const float* __restrict__ slab, int nblocks,
                                                                   const float* __restrict__ gamma,

@@ -45,6 +45,8 @@ struct ThinArgs {
     int act;
     float slope;
     FastDiv d_W, d_W4;   // by W and by 2W / 4 (float4 groups per image row)
+    BnFin fin;           // convT fwd: the producer BatchNorm is finalised in this kernel's prologue (C > 0; igemm.h)
+    float* acc_save;     // convT bwd: the backward sums also go to the accumulators behind this save block (or null)
 };
 
 // Branch-free helpers: the modes are folded into coefficients (identity when a transform is absent) and the
@@ -327,10 +329,17 @@ __global__ __launch_bounds__(TH_THREADS) void thin_convT_fwd_k(ThinArgs a) {
         for (int c = 0; c < C; ++c)
             t[c * plane + ah * ws + aw] = fmaxf(fmaf(vn[c] - coef[c], coef[2 * C + c], coef[3 * C + c]), thr);
     };
+    BnFinRegs finr;
+    bnfin_issue<false>(a.fin, finr);
     load_own(blockIdx.x, vA);
     load_own(min((int)blockIdx.x + g, last), vB);
     for (int e = tid; e < 2 * tile_n; e += TH_THREADS) smem[e] = 0.f;
-    th_in_coef<C>(a.in, coef);
+    if (a.fin.C > 0) {  // every workgroup finalises the producer BatchNorm from its accumulators (requested above)
+        bnfin_forward<TH_THREADS>(a.fin, finr, coef, coef + 4 * C + 4);
+        if (tid == 0) coef[4 * C] = a.in.relu ? 0.f : -__builtin_inff();
+    } else {
+        th_in_coef<C>(a.in, coef);
+    }
     float wv[C][9];
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -471,6 +480,7 @@ __global__ __launch_bounds__(TH_THREADS) void thin_convT_bwd_k(ThinArgs a) {
         sl[1] = sums[C + tid];
         sl[2] = 0.f;
         sl[3] = 0.f;
+        if (a.acc_save != nullptr) bnacc_add_bwd(a.acc_save, C, tid, sums[tid], sums[C + tid]);
     }
 }
 
@@ -499,6 +509,7 @@ struct MidWgArgs {
     int Hp, Wp;       // padded G image (halo = ph, pw on the low side)
     float slope;
     FastDiv dS_HW, dS_W, dS_CHW, dG_HW, dG_W, dG_CHW, d_KK, d_KW;
+    BnFin fin;        // the BatchNorm behind the layer is finalised (backward) in this kernel's prologue (C > 0; igemm.h)
 };
 #define MID_KSW 4  // k-steps per wave: SBR * SH * SW <= 64
 
@@ -544,6 +555,8 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
             if (!S_GRAD) gy[j] = pg2[e];
         }
     };
+    BnFinRegs finr;
+    bnfin_issue<true>(a.fin, finr);
     load(blockIdx.x, sA, sAy, gA, gAy);
     load(blockIdx.x + g, sB, sBy, gB, gBy);
 
@@ -555,11 +568,15 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
         cin[e] = v;
     }
     if (tid == 0) cin[4 * Cin_t] = (tin.mode == TR_BN && tin.relu) ? 0.f : -__builtin_inff();
-    for (int e = tid; e < 4 * Cgr_t; e += TH_THREADS) {
-        const int q = e / Cgr_t, c = e - q * Cgr_t;
-        float v = q == 1 ? 1.f : 0.f;
-        if (tgr.mode == TR_GRAD_BN) v = tgr.coef[(q == 0 ? 0 : 3 + q) * Cgr_t + c];
-        cgr[e] = v;
+    if (a.fin.C > 0) {  // every workgroup finalises the BatchNorm's backward from its accumulators (requested above)
+        bnfin_backward<TH_THREADS>(a.fin, finr, cgr, cgr + 4 * Cgr_t + 4);
+    } else {
+        for (int e = tid; e < 4 * Cgr_t; e += TH_THREADS) {
+            const int q = e / Cgr_t, c = e - q * Cgr_t;
+            float v = q == 1 ? 1.f : 0.f;
+            if (tgr.mode == TR_GRAD_BN) v = tgr.coef[(q == 0 ? 0 : 3 + q) * Cgr_t + c];
+            cgr[e] = v;
+        }
     }
     // per-slot constants: channel and LDS destination (a round's S and G are contiguous in global memory:
     // [sample][channel][pixel], and S keeps that layout in LDS)
@@ -938,9 +955,16 @@ __global__ __launch_bounds__(TH_THREADS) void mid_conv_k(IgArgs a) {
         float* sl = a.slab + ((int64_t)blockIdx.x * g.N + tid) * 4;
         if (EPBN) {
             sl[0] = t1; sl[1] = t2; sl[2] = 0.f; sl[3] = 0.f;
+            if (a.acc_save != nullptr) bnacc_add_bwd(a.acc_save, g.N, tid, t1, t2);
         } else {
-            sl[0] = a.bias != nullptr ? a.bias[tid] : 0.f;
-            sl[1] = t1; sl[2] = t2; sl[3] = red[128];  // every wave counted the workgroup's samples
+            const float bp = a.bias != nullptr ? a.bias[tid] : 0.f, cn = red[128];  // every wave counted the workgroup's samples
+            sl[0] = bp;
+            sl[1] = t1; sl[2] = t2; sl[3] = cn;
+            if (a.acc_save != nullptr) {
+                const float dd = t1 / cn, pv = a.acc_pivot[tid];
+                bnacc_add_fwd(a.acc_save, g.N, tid, cn, bp + dd, fmaxf(t2 - t1 * dd, 0.f), pv);
+                if (blockIdx.x == 0) a.acc_save[7 * g.N + tid] = pv;
+            }
         }
     }
 }

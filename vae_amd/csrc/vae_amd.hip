@@ -66,6 +66,10 @@ struct Ctx {
     mutable int last_blocks;  // blocks that wrote the per-channel slab consumed by the next BN finalize
     mutable LinWgMulti lin_wg;  // Linear weight gradients deferred to one launch at the end of backward
     mutable WgFinMulti wg_fin;  // conv weight-gradient partial reductions, likewise
+    // a virtual BatchNorm whose finalize has been handed to the prologue of its first consumer kernel (igemm.h: BnFin);
+    // 0: none, 1: forward, 2: backward.  Whatever runs next and cannot take it launches bnv_finalize_*_k (bn_flush_pending).
+    mutable int pend;
+    mutable BnFin pend_fin;
 };
 static inline int ref_space(int64_t r) { return (int)(r >> 56); }
 static inline int64_t ref_off(int64_t r) { return r & (((int64_t)1 << 56) - 1); }
@@ -486,7 +490,7 @@ static IgPlan plan_gather(const IgGeom& g, int B) {
     if (g.so_h * g.so_w > 4) { p.SB = 0; return p; }
     fill_classes(g, cls, &wsum, &tsum);
     const int per_in = g.Cin * g.Hp * g.Wp, per_out = g.N * g.OH * g.OW + g.OH * g.OW;  // (+ pixel table)
-    const int coef = 8 * (g.Cin + g.N) + g.Np + 8 + tsum;  // (+ the set-up's weight-base table, one int per tap-table row)
+    const int coef = 8 * (g.Cin + g.N) + g.Np + 8 + tsum + 4 * g.Np;  // (+ the set-up's weight-base table, one int per tap-table row; + the workgroup's running statistics)
     const int fixed = wsum + tsum + coef;
     int fit = (IG_LDS_BUDGET_FLOATS - fixed - 4) / (per_in + per_out);
     if (fit > 64) fit = 64;
@@ -702,7 +706,7 @@ static size_t thin_lds_bytes(int H, int W, int kernel) {  // kernel: 0 conv fwd,
     switch (kernel) {
         case 0: return (size_t)(2 * img) * sizeof(float);
         case 1: return (size_t)(2 * img + 8 * TH_C + 1024 + TH_THREADS * TH_MM_STRIDE + 16) * sizeof(float);
-        case 2: return (size_t)(2 * TH_C * (H + 1) * (W + 1) + 8 * TH_C) * sizeof(float);
+        case 2: return (size_t)(2 * TH_C * (H + 1) * (W + 1) + 8 * TH_C + BNFIN_SCR_FLOATS + 8) * sizeof(float);  // (+ finalize prologue scratch)
         default: return (size_t)(2 * img + 8 * TH_C + 1024 + TH_THREADS * TH_MM_STRIDE + 16) * sizeof(float);
     }
 }
@@ -959,6 +963,22 @@ static int gather_direct_nd(const IgGeom& g, const IgClass* cls, int ncls) {
     return g.N == 1 ? 1 : (kmax <= 36 && g.N <= 8) ? 8 : 0;
 }
 
+static int bn_flush_pending(const Ctx& c);
+static int bn_take_pending(const Ctx& c, int dir, const float* coef, BnFin* out);
+static int bnfin_enabled();
+static_assert(VAE_BN_ACC_FLOATS(1) == BNACC_FLOATS(1), "include/vae_amd.h and igemm.h disagree on the accumulator block");
+// the BatchNorm of C channels whose save block `ref` is (op flagged VAE_F_BN_ACC) takes fixed-point accumulators
+static bool bn_acc_ok(const vae_op& op, int C) {
+    return (op.flags & VAE_F_BN_ACC) && g_world <= 1 && C <= BNFIN_MAXC && bnfin_enabled();
+}
+// Puts a BnFin that the launch cannot use back as a launch of its own.
+static int bn_untake(const Ctx& c, BnFin* f, int dir) {
+    if (f->C == 0) return VAE_OK;
+    c.pend = dir;
+    c.pend_fin = *f;
+    f->C = 0; f->slab = nullptr;
+    return bn_flush_pending(c);
+}
 static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const IgPlan p = plan_gather(a.g, c.B);
     if (p.SB < 1) VAE_FAIL(VAE_EINVAL, "%s: layer does not fit the fused conv kernel's LDS budget", what);
@@ -1002,6 +1022,10 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
         const bool gradin = a.in.mode >= TR_GRAD_BN;
         const int actv = gradin ? a.in.act : a.act;
         if (mid_on && mid_conv_geom_ok(q) && (!gradin || a.act == VAE_ACT_NONE) && (a.ep_mode == EP_PLAIN || gradin)) {
+            {
+                const int frc = bn_untake(c, &a.fin, 1);  // (mid_conv_k has no finalize prologue)
+                if (frc) return frc;
+            }
             int grid = mid_grid(c.B);
             if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
             const size_t mbytes = (size_t)(2 * q.Cin * q.Hp * q.Wp + 4 * q.Cin + 4 + 4 * q.N + 4 + 136) * sizeof(float);
@@ -1029,6 +1053,10 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
     const int g_max = IG_MAX_GRID;
     const int grid = a.nchunks < g_max ? a.nchunks : g_max;
     const size_t bytes = (size_t)p.total * sizeof(float);
+    if (a.fin.C > 0 && p.lds_out < BNFIN_SCR_FLOATS) {  // (the finalize prologue's scratch overlays the output tile)
+        const int frc = bn_untake(c, &a.fin, 1);
+        if (frc) return frc;
+    }
     const bool grad = a.in.mode >= TR_GRAD_BN;
     const int nd = gather_direct_nd(a.g, a.cls, a.ncls);
     // (the ND > 0 instances compute on the vector ALU in fp32 whatever the compute dtype)
@@ -1053,7 +1081,7 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
                                      (double)a.g.N * a.g.OH * a.g.OW * (a.ep_mode == EP_BNGRAD ? 2 : 1)) +
                       (double)a.g.Cin * a.g.KH * a.g.KW * a.g.N));
     VAE_LAUNCH_CHECK(what);
-    if (a.slab != nullptr) c.last_blocks = a.nchunks;
+    if (a.slab != nullptr) c.last_blocks = grid;  // one row per workgroup
     return VAE_OK;
 }
 
@@ -1092,11 +1120,15 @@ static int conv_forward_fused(const Ctx& c, const vae_op& op, int training) {
     a.act = op.act; a.slope = op.f[0];
     a.ep_mode = EP_PLAIN; a.ep_y = nullptr; a.ep_coef = nullptr; a.ep_relu = 0;
     a.slab = nullptr;
+    if (!ok) return VAE_EINVAL;
+    // the producer BatchNorm's pending finalize goes into this layer's kernel (or is launched now)
+    if ((rc = bn_take_pending(c, 1, a.in.coef, &a.fin)) != VAE_OK) return rc;
     const int thin = op.r[8] < 0 ? thin_kind(g, T) : 0;  // (the thin kernels take no BatchNorm statistics of their output)
+    if (a.fin.C > 0 && thin == 1 && (rc = bn_untake(c, &a.fin, 1)) != VAE_OK) return rc;
     if (thin != 0 && (thin == 2 || op.r[7] < 0)) {
-        if (!ok) return VAE_EINVAL;
         ThinArgs t;
         memset(&t, 0, sizeof(t));
+        t.fin = a.fin;
         t.in = a.in; t.w = a.w; t.bias = a.bias; t.out = a.out; t.B = c.B; t.act = op.act; t.slope = op.f[0];
         t.H = thin == 1 ? g.OH : g.H; t.W = thin == 1 ? g.OW : g.W;
         t.d_W = mk_fdiv((uint32_t)t.W); t.d_W4 = mk_fdiv((uint32_t)(2 * t.W / 4));
@@ -1107,10 +1139,15 @@ static int conv_forward_fused(const Ctx& c, const vae_op& op, int training) {
         VAE_LAUNCH_CHECK("thin conv forward");
         return VAE_OK;
     }
+    a.acc_save = nullptr; a.acc_pivot = nullptr;
     if (op.r[8] >= 0 && training) {
         const IgPlan p = plan_gather(a.g, c.B);
         if (p.SB >= 1 && slab_ok(c, op.r[6], (c.B + p.SB - 1) / p.SB, g.Cout)) return VAE_EINVAL;
         a.slab = resolve(c, op.r[6], 4 * g.Cout, "conv.slab", &ok);
+        if (bn_acc_ok(op, g.Cout) && op.r[9] >= 0) {  // the statistics also go to the BatchNorm's accumulators
+            a.acc_save = resolve(c, op.r[8], (int64_t)8 * g.Cout + BNACC_FLOATS(g.Cout), "conv.out_bn+accumulators", &ok);
+            a.acc_pivot = resolve(c, op.r[9], g.Cout, "conv.out_bn.running_mean", &ok);
+        }
     }
     if (!ok) return VAE_EINVAL;
     return launch_igemm_gather(c, a, "igemm_gather_k(fwd)");
@@ -1147,6 +1184,7 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     float* dx = resolve_opt(c, op.r[2], nin, "conv.din", &ok);
     if (!ok) return VAE_EINVAL;
 
+    if (op.r[8] < 0 && (rc = bn_flush_pending(c)) != VAE_OK) return rc;
     {   // thin outer layers: one streaming kernel for the whole backward of the layer (thin.h)
         const int thin = op.r[8] < 0 ? thin_kind(g, T) : 0;
         if ((thin == 1 && dx == nullptr && op.r[7] < 0) || thin == 2) {
@@ -1168,6 +1206,8 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
                     if (slab_ok(c, op.r[6], grid, g.Cin)) return VAE_EINVAL;
                     t.slab = resolve(c, op.r[6], 4 * g.Cin, "conv.slab", &ok);
                     t.ep_coef = tin.coef; t.ep_relu = tin.relu;
+                    if (bn_acc_ok(op, g.Cin))
+                        t.acc_save = resolve(c, op.r[7], (int64_t)8 * g.Cin + BNACC_FLOATS(g.Cin), "conv.in_bn+accumulators", &ok);
                     if (!ok) return VAE_EINVAL;
                 }
                 THIN_LAUNCH(thin_convT_bwd_k, op.act, grid, thin_lds_bytes(t.H, t.W, 3), c.s, t);
@@ -1214,9 +1254,12 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     wa.nchunks = (c.B + wp.SB - 1) / wp.SB;
     int mid_inst = 0;
     const int mid_sbr = g_bf16 ? 0 : mid_wgrad_sbr(wa.Sc, wa.SH, wa.SW, wa.Gc, wa.GH, wa.GW, g.KH, g.KW, wp.MT, wp.NT, &mid_inst);
+    if (!(mid_sbr > 0 && (op.act == VAE_ACT_NONE || op.act == VAE_ACT_LEAKY)) && (rc = bn_flush_pending(c)) != VAE_OK) return rc;
     if (mid_sbr > 0 && (op.act == VAE_ACT_NONE || op.act == VAE_ACT_LEAKY)) {
         MidWgArgs m;
         memset(&m, 0, sizeof(m));
+        // the BatchNorm behind this layer: its backward finalize runs in this kernel's prologue
+        if ((rc = bn_take_pending(c, 2, tg.coef, &m.fin)) != VAE_OK) return rc;
         m.S = wa.S; m.G = wa.G; m.want_bias = db != nullptr; m.B = c.B; m.SBR = mid_sbr;
         m.Sc = wa.Sc; m.SH = wa.SH; m.SW = wa.SW; m.Gc = wa.Gc; m.GH = wa.GH; m.GW = wa.GW;
         m.KH = g.KH; m.KW = g.KW; m.sh = g.sh; m.sw = g.sw; m.ph = g.ph; m.pw = g.pw; m.Hp = wp.Hp; m.Wp = wp.Wp;
@@ -1231,7 +1274,7 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
         if (!ok) return VAE_EINVAL;
         const int nS = mid_sbr * wa.Sc * wa.SH * wa.SW, imgG = mid_sbr * wa.Gc * wp.Hp * wp.Wp;
         const int nGr = mid_sbr * wa.Gc * wa.GH * wa.GW;
-        int fl = 2 * nS + 2 * imgG + 4 * (wa.Sc + wa.Gc) + 8;
+        int fl = 2 * nS + 2 * imgG + 4 * (wa.Sc + wa.Gc) + 8 + BNFIN_SCR_FLOATS + 8;  // (+ the finalize prologue's scratch)
         if (fl < 4 * 5 * 256) fl = 4 * 5 * 256;          // the cross-wave reduction's passes of five tiles
         if (fl < (nS > nGr ? nS : nGr)) fl = nS > nGr ? nS : nGr;  // the bias partials of a round
         const size_t bytes = (size_t)fl * sizeof(float);
@@ -1270,15 +1313,55 @@ static int conv_backward_fused(const Ctx& c, const vae_op& op) {
     a.in = tg;
     a.out = dx; a.w = w; a.bias = nullptr; a.act = VAE_ACT_NONE; a.slope = 0.f;
     a.ep_mode = EP_PLAIN; a.ep_y = nullptr; a.ep_coef = nullptr; a.ep_relu = 0; a.slab = nullptr;
+    memset(&a.fin, 0, sizeof(a.fin));
+    a.acc_save = nullptr; a.acc_pivot = nullptr;
     if (op.r[7] >= 0) {  // the producer's BatchNorm is virtual: mask by its ReLU and take its backward sums here
         a.ep_mode = EP_BNGRAD;
         a.ep_y = tin.src; a.ep_coef = tin.coef; a.ep_relu = tin.relu;
         const IgPlan p = plan_gather(a.g, c.B);
         if (p.SB >= 1 && slab_ok(c, op.r[6], (c.B + p.SB - 1) / p.SB, g.Cin)) return VAE_EINVAL;
         a.slab = resolve(c, op.r[6], 4 * g.Cin, "conv.slab", &ok);
+        if (bn_acc_ok(op, g.Cin))
+            a.acc_save = resolve(c, op.r[7], (int64_t)8 * g.Cin + BNACC_FLOATS(g.Cin), "conv.in_bn+accumulators", &ok);
         if (!ok) return VAE_EINVAL;
     }
     return launch_igemm_gather(c, a, "igemm_gather_k(dgrad)");
+}
+
+// VAE_AMD_BNFIN=0: every virtual BatchNorm is finalised by a launch of its own (bnv_finalize_*_k), as before round 3
+static int bnfin_enabled() {
+    const char* e = getenv("VAE_AMD_BNFIN");
+    return (e != nullptr && *e) ? atoi(e) != 0 : 1;
+}
+// The pending finalize as a launch of its own: the op behind the BatchNorm cannot do it in its prologue.
+static int bn_flush_pending(const Ctx& c) {
+    if (c.pend == 0) return VAE_OK;
+    const BnFin& f = c.pend_fin;
+    const int dir = c.pend;
+    c.pend = 0;
+    if (dir == 1) {
+        hipLaunchKernelGGL(bnv_finalize_fwd_k, dim3(f.C), dim3(BNV_THREADS), 0, c.s, f.slab, f.nrows, f.gamma, f.beta, f.save,
+                           f.rmean, f.rvar, f.C, f.eps, f.momentum, f.training, (float*)nullptr);
+        VAE_TBYTES(16.0 * f.C * (f.nrows + 1));
+        VAE_LAUNCH_CHECK("bnv_finalize_fwd_k");
+    } else {
+        hipLaunchKernelGGL(bnv_finalize_bwd_k, dim3(f.C), dim3(BNV_THREADS), 0, c.s, f.slab, f.nrows, f.save, f.dgamma, f.dbeta,
+                           f.C, (int64_t)f.n_local, (float*)nullptr, (const float*)nullptr);
+        VAE_TBYTES(16.0 * f.C * (f.nrows + 1));
+        VAE_LAUNCH_CHECK("bnv_finalize_bwd_k");
+    }
+    return VAE_OK;
+}
+// Hands the pending finalize to a consumer kernel whose coefficient block is `coef` (the BatchNorm's save block).
+// Returns the BnFin to pass (C = 0: none) and clears the pending state; a pending finalize of ANOTHER BatchNorm or
+// direction is flushed first.
+static int bn_take_pending(const Ctx& c, int dir, const float* coef, BnFin* out) {
+    memset(out, 0, sizeof(*out));
+    if (c.pend == 0) return VAE_OK;
+    if (c.pend != dir || c.pend_fin.save != coef) return bn_flush_pending(c);
+    *out = c.pend_fin;
+    c.pend = 0;
+    return VAE_OK;
 }
 
 static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
@@ -1297,6 +1380,20 @@ static int bn_virtual_forward(const Ctx& c, const vae_op& op, int training) {
     float* slab = resolve(c, op.r[9], (int64_t)4 * C * ((nblocks > 0 ? nblocks : 1) + (dp ? g_world : 0)), "bn.slab", &ok);
     if (!ok) return VAE_EINVAL;
     if (training && nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no producer statistics");
+    if (!training || bn_acc_ok(op, C)) {
+        if (bn_acc_ok(op, C)) resolve(c, op.r[6], (int64_t)8 * C + BNACC_FLOATS(C), "bn.save+accumulators", &ok);
+        if (!ok) return VAE_EINVAL;
+    }
+    if (!dp && C <= BNFIN_MAXC && bnfin_enabled() && (!training || bn_acc_ok(op, C))) {  // finalised by the consumer kernel's prologue (or by bn_flush_pending)
+        BnFin& f = c.pend_fin;
+        memset(&f, 0, sizeof(f));
+        f.slab = slab; f.nrows = nblocks; f.C = C; f.training = training ? 1 : 0;
+        f.gamma = gamma; f.beta = beta; f.save = save; f.rmean = rm; f.rvar = rv;
+        f.eps = op.f[0]; f.momentum = op.f[1];
+        c.pend = 1;
+        c.last_blocks = 0;
+        return VAE_OK;
+    }
     const float* rows = slab;
     int nrows = nblocks;
     if (dp) {
@@ -1328,6 +1425,17 @@ static int bn_virtual_backward(const Ctx& c, const vae_op& op) {
     if (!ok) return VAE_EINVAL;
     if (nblocks < 1) VAE_FAIL(VAE_EINVAL, "bn(virtual): no consumer gradient statistics");
     const int64_t n_local = (int64_t)c.B * HW;
+    if (bn_acc_ok(op, C)) {
+        resolve(c, op.r[6], (int64_t)8 * C + BNACC_FLOATS(C), "bn.save+accumulators", &ok);
+        if (!ok) return VAE_EINVAL;
+        BnFin& f = c.pend_fin;
+        memset(&f, 0, sizeof(f));
+        f.slab = slab; f.nrows = nblocks; f.C = C; f.training = 1;
+        f.save = save; f.dgamma = dgamma; f.dbeta = dbeta; f.n_local = (float)n_local;
+        c.pend = 2;
+        c.last_blocks = 0;
+        return VAE_OK;
+    }
     if (dp) {
         float* gath = slab + (int64_t)4 * C * nblocks;
         float* mine = gath + (int64_t)g_rank * 4 * C;
@@ -2018,7 +2126,8 @@ static int elbo_forward(const Ctx& c, const vae_op& op) {
     return elbo_fwd_impl(c.s, xr, tg, mu, lv, out, part, c.B, nps, op.d[1], op.d[2], latent,
                          (op.flags & VAE_F_BCE) ? 1 : 0, op.d[5], !(op.flags & VAE_F_LOSS_IN_BWD));
 }
-static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullptr, int64_t zero_n = 0) {
+static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullptr, int64_t zero_n = 0,
+                         const ZeroRanges* zr = nullptr) {
     const int nps = op.d[0], latent = op.d[3];
     bool ok = true;
     const float* xr = resolve(c, op.r[0], (int64_t)c.B * nps, "elbo.x_rec", &ok);
@@ -2035,7 +2144,8 @@ static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullp
     // KL gradients are folded into the REPARAM op's backward (VAE_F_KL_GRAD)
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid((int64_t)c.B * nps)), dim3(256), 0, c.s, xr, tg, nullptr, nullptr, gs,
                        dxr, nullptr, nullptr, (int64_t)c.B, nps, (int64_t)op.d[1], (int64_t)op.d[2], latent,
-                       (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n, fin_part, fin_out, VAE_ELBO_BLOCKS, op.d[5]);
+                       (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n, fin_part, fin_out, VAE_ELBO_BLOCKS, op.d[5],
+                       zr != nullptr ? *zr : ZeroRanges{});
     VAE_TBYTES(12.0 * (double)c.B * nps + 4.0 * (double)zero_n);
     VAE_LAUNCH_CHECK("elbo_bwd_k");
     return VAE_OK;
@@ -2054,10 +2164,64 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     c->last_blocks = 0;
     c->lin_wg.n = 0;
     c->wg_fin.n = 0;
+    c->pend = 0;
+    memset(&c->pend_fin, 0, sizeof(c->pend_fin));
     return VAE_OK;
 }
 
+// Clears the save blocks + accumulators of every BatchNorm flagged VAE_F_BN_ACC: one memset when they lie back to back
+// (each padded to 64 floats: what vae_amd/program.py allocates), else one per block.
+// zr != nullptr: instead, return the accumulator ranges (not the save blocks: the backward pass still reads them) for a
+// kernel that clears them on its way (elbo_bwd_k); more than ZERO_RANGES_MAX blocks are cleared by memsets here.
+static int bn_zero_accumulators(const Ctx& c, const vae_op* ops, int n_ops, ZeroRanges* zr = nullptr) {
+    if (zr != nullptr) zr->cnt = 0;
+    if (g_world > 1 || !bnfin_enabled()) return VAE_OK;
+    int64_t lo = -1, hi = -1, sum = 0;
+    int nb = 0;
+    bool ok = true;
+    for (int i = 0; i < n_ops; ++i) {
+        const vae_op& op = ops[i];
+        if (op.kind != VAE_OP_BN || !(op.flags & VAE_F_BN_ACC) || op.d[0] < 1 || op.d[0] > BNFIN_MAXC) continue;
+        const int64_t n = (int64_t)8 * op.d[0] + BNACC_FLOATS(op.d[0]), npad = (n + 63) / 64 * 64;
+        if (ref_space(op.r[6]) != 0) VAE_FAIL(VAE_EINVAL, "bn: accumulator blocks live in the WORK space");
+        resolve(c, op.r[6], n, "bn.save+accumulators", &ok);
+        if (!ok) return VAE_EINVAL;
+        const int64_t off = ref_off(op.r[6]);
+        if (zr != nullptr) {
+            if (zr->cnt < ZERO_RANGES_MAX) {
+                zr->p[zr->cnt] = c.bases[0] + off + 8 * op.d[0];
+                zr->n[zr->cnt] = BNACC_FLOATS(op.d[0]);
+                ++zr->cnt;
+            } else {
+                VAE_HIP(hipMemsetAsync(c.bases[0] + off + 8 * op.d[0], 0, (size_t)BNACC_FLOATS(op.d[0]) * sizeof(float), c.s));
+            }
+            continue;
+        }
+        if (lo < 0 || off < lo) lo = off;
+        if (off + n > hi) hi = off + n;
+        sum += npad;
+        ++nb;
+    }
+    if (nb == 0) return VAE_OK;
+    if ((hi - lo + 63) / 64 * 64 == sum) {  // (at the start of a forward pass the save blocks are dead as well)
+        VAE_HIP(hipMemsetAsync(c.bases[0] + lo, 0, (size_t)(hi - lo) * sizeof(float), c.s));
+        return VAE_OK;
+    }
+    for (int i = 0; i < n_ops; ++i) {
+        const vae_op& op = ops[i];
+        if (op.kind != VAE_OP_BN || !(op.flags & VAE_F_BN_ACC) || op.d[0] < 1 || op.d[0] > BNFIN_MAXC) continue;
+        VAE_HIP(hipMemsetAsync(c.bases[0] + ref_off(op.r[6]), 0, (size_t)(8 * op.d[0] + BNACC_FLOATS(op.d[0])) * sizeof(float), c.s));
+    }
+    return VAE_OK;
+}
+static inline bool fused_conv_op(const vae_op& op) {
+    return (op.kind == VAE_OP_CONV || op.kind == VAE_OP_CONVT) && (op.flags & VAE_F_FUSED);
+}
 static int forward_op(const Ctx& c, const vae_op& op, int i, int training) {
+    if (c.pend && !fused_conv_op(op)) {
+        const int rc = bn_flush_pending(c);
+        if (rc) return rc;
+    }
     switch (op.kind) {
         case VAE_OP_CONV:
         case VAE_OP_CONVT: return (op.flags & VAE_F_FUSED) ? conv_forward_fused(c, op, training) : conv_forward(c, op);
@@ -2079,7 +2243,11 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
         static thread_local SqProgram sq;
         if (sq_use(ops, n_ops, B, &sq)) return sq_forward(c, ops, &sq, training);
     }
+    // training == 2: the caller vouches that the BatchNorm accumulators are zero already (a fused train step: the
+    // workspace starts zeroed and every backward pass that begins with the ELBO op clears them again)
+    if (training == 1 && (rc = bn_zero_accumulators(c, ops, n_ops)) != VAE_OK) return rc;
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
+        if (c.pend && !fused_conv_op(ops[i]) && (rc = bn_flush_pending(c)) != VAE_OK) break;
         if (c.fc && fc_kind(ops[i])) {  // a run of Linear / reparam ops: one launch (fc.h)
             int n = 1;
             while (i + n < n_ops && fc_kind(ops[i + n])) ++n;
@@ -2094,6 +2262,7 @@ extern "C" int vae_run_forward(const vae_op* ops, int n_ops, float* const* bases
             rc = forward_op(c, ops[i], i, training);
         }
     }
+    if (rc == VAE_OK) rc = bn_flush_pending(c);
     return rc;
 }
 
@@ -2110,10 +2279,12 @@ extern "C" int vae_time_forward(const vae_op* ops, int n_ops, float* const* base
     for (; made <= n_ops; ++made)
         if (hipEventCreate(&ev[made]) != hipSuccess) break;
     if (made <= n_ops) rc = VAE_EHIP, vae_set_error("time_forward: hipEventCreate failed");
+    if (rc == VAE_OK && training) rc = bn_zero_accumulators(c, ops, n_ops);
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i) {
         if (hipEventRecord(ev[i], c.s) != hipSuccess) { rc = VAE_EHIP; vae_set_error("hipEventRecord failed"); break; }
         rc = forward_op(c, ops[i], i, training);
     }
+    if (rc == VAE_OK) rc = bn_flush_pending(c);
     if (rc == VAE_OK && (hipEventRecord(ev[n_ops], c.s) != hipSuccess || hipEventSynchronize(ev[n_ops]) != hipSuccess))
         rc = VAE_EHIP, vae_set_error("time_forward: event record/synchronize failed");
     for (int i = 0; i < n_ops && rc == VAE_OK; ++i)
@@ -2183,8 +2354,14 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
     if (zero_grads && !zero_in_elbo) VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
     for (int i = op_end - 1; i >= op_begin && rc == VAE_OK; --i) {
         const vae_op& op = ops[i];
+        if (c.pend && !fused_conv_op(op) && (rc = bn_flush_pending(c)) != VAE_OK) break;
         if (zero_in_elbo && i == op_end - 1) {
-            rc = elbo_backward(c, op, bases[2], base_sizes[2]);
+            // (the BatchNorm accumulators are cleared on the way: scattered blocks by memsets, behind the forward
+            // pass whose consumers were their last readers)
+            ZeroRanges zr;
+            memset(&zr, 0, sizeof(zr));
+            rc = bn_zero_accumulators(c, ops, n_ops, &zr);
+            if (rc == VAE_OK) rc = elbo_backward(c, op, bases[2], base_sizes[2], &zr);
             continue;
         }
         if (c.fc && fc_kind(op)) {  // a run of Linear / reparam ops: the input gradients in one launch (fc.h)
@@ -2218,6 +2395,7 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
             default: vae_set_error("op %d: unknown kind %d", i, op.kind); rc = VAE_EINVAL;
         }
     }
+    if (rc == VAE_OK) rc = bn_flush_pending(c);
     if (rc == VAE_OK) rc = flush_linear_wgrads(c);
     if (rc == VAE_OK) rc = flush_wgrad_finalize(c);
     return rc;

@@ -123,7 +123,7 @@ class ProgramBuilder:
         """bn: holder with .weight .bias .running_mean .running_var"""
         assert x.n == C * HW and x.ld == x.n
         y = self.act(C * HW)
-        save = self.fixed(8 * C)
+        save = -1  # allocated in build(): the save blocks (+ accumulators) of all BatchNorms lie back to back
         op = self._op(L.OP_BN, flags=L.F_BN_RELU if relu else 0,
                       r=(x.ref, y.ref, x.gref, y.gref, self.param(bn.weight), self.param(bn.bias), save,
                          self.state(bn.running_mean), self.state(bn.running_var)),
@@ -200,6 +200,9 @@ class ProgramBuilder:
             p, c = prod[0], cons[0]
             if not (p.flags & L.F_FUSED and c.flags & L.F_FUSED):
                 continue
+            if bn.flags & L.F_BN_ACC:
+                p.flags |= L.F_BN_ACC
+                c.flags |= L.F_BN_ACC
             c.r[0], c.r[2], c.r[7] = bn.r[0], bn.r[2], bn.r[6]
             if bn.flags & L.F_BN_RELU:
                 c.flags |= L.F_IN_RELU
@@ -219,7 +222,22 @@ class ProgramBuilder:
         self.ops[0].r[11] = self.fixed(need)
         return True
 
+    def _bn_blocks(self):
+        """Save blocks of the BatchNorm ops, back to back; blocks of <= 16 channels are followed by the fixed-point
+        accumulators their statistics are summed in (include/vae_amd.h: VAE_F_BN_ACC), so that the executor clears them
+        all with one memset and finalises such a BatchNorm in the prologue of its first consumer kernel."""
+        lo = self.work_size
+        for op in self.ops:
+            if op.kind == L.OP_BN:
+                C = op.d[0]
+                acc = C <= L.BN_ACC_MAXC
+                op.r[6] = self.fixed(8 * C + (L.bn_acc_floats(C) if acc else 0))
+                if acc:
+                    op.flags |= L.F_BN_ACC
+        self.bn_arena = (lo, self.work_size - lo)  # floats of WORK: every save block and accumulator
+
     def build(self):
+        self._bn_blocks()
         self.seq1d = self._seq1d()
         if not self.seq1d and os.environ.get("VAE_AMD_UNFUSED", "0") != "1":
             self._fuse()
@@ -229,6 +247,8 @@ class ProgramBuilder:
         arr = (L.VaeOp * len(self.ops))(*self.ops)
         prog = CompiledProgram(arr, len(self.ops), self.B, self.work_size, self.inputs, self.outputs)
         prog.seq1d = self.seq1d
+        prog.bn_arena = self.bn_arena
+        prog.ends_with_elbo = len(self.ops) > 0 and self.ops[-1].kind == L.OP_ELBO
         return prog
 
 
@@ -239,6 +259,22 @@ class CompiledProgram:
         self.n_bases = L.SP_EXT0 + len(inputs)
         self._bases = (ctypes.c_void_p * self.n_bases)()
         self._sizes = (ctypes.c_int64 * self.n_bases)()
+        # The workspace (by address) whose BatchNorm accumulators are known to be zero: a training forward over it may
+        # then skip its memset (vae_run_forward training = 2).  Any forward dirties them; a whole backward pass of a
+        # program that ends with the ELBO op clears them again (include/vae_amd.h).
+        self._clean_ptr = None
+        self.bn_arena, self.ends_with_elbo = (0, 0), False
+
+    def ensure_clean(self, work):
+        """Zeroes the BatchNorm accumulators of `work` unless they are known to be clean; afterwards they are."""
+        if self._clean_ptr != work.data_ptr():
+            lo, n = self.bn_arena
+            if n:
+                work[lo:lo + n].zero_()
+            self._clean_ptr = work.data_ptr()
+
+    def _after_backward(self, work, whole=True):
+        self._clean_ptr = work.data_ptr() if (whole and self.ends_with_elbo) else None
 
     def new_workspace(self, device):
         return torch.empty(self.work_size, dtype=torch.float32, device=device)
@@ -258,13 +294,17 @@ class CompiledProgram:
 
     def forward(self, work, params, state, ext, training, stream=None):
         self._bind(work, params, None, state, ext)
+        clean = training and self._clean_ptr == work.data_ptr()
+        self._clean_ptr = None
         L.check(L.lib().vae_run_forward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
-                                        1 if training else 0, stream if stream is not None else L.stream_ptr()),
+                                        (2 if clean else 1) if training else 0,
+                                        stream if stream is not None else L.stream_ptr()),
                 "vae_run_forward")
 
     def time_forward(self, work, params, state, ext, training, stream=None):
         """Forward with a HIP event between ops on the launch stream; returns per-op device ms (list)."""
         self._bind(work, params, None, state, ext)
+        self._clean_ptr = None
         ms = (ctypes.c_float * self.n_ops)()
         L.check(L.lib().vae_time_forward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                          1 if training else 0, stream if stream is not None else L.stream_ptr(), ms),
@@ -278,6 +318,7 @@ class CompiledProgram:
         cap = 40
         ms, nbytes = (ctypes.c_float * cap)(), (ctypes.c_double * cap)()
         tags, n = ctypes.create_string_buffer(8 * cap), ctypes.c_int32(0)
+        self._clean_ptr = None
         L.check(L.lib().vae_time_seq(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                      stream if stream is not None else L.stream_ptr(), ms, nbytes, tags, cap,
                                      ctypes.byref(n)), "vae_time_seq")
@@ -292,6 +333,7 @@ class CompiledProgram:
         L.check(L.lib().vae_time_step(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                       stream if stream is not None else L.stream_ptr(), L.ptr(m), L.ptr(v), L.ptr(hyper),
                                       L.ptr(tick), ms, nbytes, flops, names, cap, ctypes.byref(n)), "vae_time_step")
+        self._after_backward(work)
         return [(names.raw[64 * k:64 * k + 64].split(b"\0")[0].decode(), ms[k], nbytes[k], flops[k]) for k in range(n.value)]
 
     def backward(self, work, params, grads, state, ext, stream=None):
@@ -299,6 +341,7 @@ class CompiledProgram:
         L.check(L.lib().vae_run_backward(self.ops, self.n_ops, self._bases, self._sizes, self.n_bases, self.B,
                                          stream if stream is not None else L.stream_ptr()),
                 "vae_run_backward")
+        self._after_backward(work)
 
     def backward_step(self, work, params, grads, state, ext, m, v, hyper, tick, stream=None, next_eps=None, rng=None):
         """Backward pass + Adam update of `params` (vae_run_backward_step); hyper = device {lr, beta1, beta2, eps}.
@@ -309,6 +352,7 @@ class CompiledProgram:
                                               L.ptr(hyper), L.ptr(tick), L.ptr(next_eps),
                                               next_eps.numel() if next_eps is not None else 0, L.ptr(rng)),
                 "vae_run_backward_step")
+        self._after_backward(work)
 
     def backward_range(self, work, params, grads, state, ext, begin, end, zero_grads, stream=None):
         """Backward over ops[begin:end) only (vae_run_backward_range): the data-parallel step's gradient buckets."""
@@ -317,6 +361,7 @@ class CompiledProgram:
                                                stream if stream is not None else L.stream_ptr(), begin, end,
                                                1 if zero_grads else 0),
                 "vae_run_backward_range")
+        self._after_backward(work, whole=bool(zero_grads) and end == self.n_ops)
 
     def grad_buckets(self):
         """Splits the program at its REPARAM op into (decoder + loss, encoder) ranges and returns

@@ -163,6 +163,7 @@ class FusedTrainStep:
                          logvar=(logvar, (model.latent_total,)))
         self.work = self.prog.new_workspace(self.device)
         self.work.zero_()
+        self.prog._clean_ptr = self.work.data_ptr()  # BatchNorm accumulators: zero
         self.x = torch.zeros((B,) + tuple(model.in_shape), device=self.device)
         self.eps = torch.zeros(B, model.latent_total, device=self.device)
         out = self.prog.scalar_view(self.work, self.out_ref, 4)
@@ -188,6 +189,8 @@ class FusedTrainStep:
         # the noise of a step is drawn by the Adam launch of the step before it (no launch of its own); the first step
         # after construction, or after the caller injected its own eps, draws it here, outside any captured graph
         ext = [self.x.view(self.B, -1), self.eps]
+        # (step() has made sure the BatchNorm accumulators of the workspace are zero: the forward pass then runs without
+        # a memset node, and the backward pass, which begins with the ELBO op, clears them again for the next step)
         self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
         draw = not self.inject_eps
         self.prog.backward_step(self.work, self.flat, self.grads, self.sflat, ext, self.m, self.v, self.hyper, self.tick,
@@ -230,6 +233,7 @@ class FusedTrainStep:
                                 f"the current one is {L.get_compute_dtype()} (build a new stepper)")
         self._refresh_hyper()
         self._first_eps()
+        self.prog.ensure_clean(self.work)  # (a no-op unless someone ran other passes over this workspace)
         if self.use_graph:
             if self.graph is None or self._captured_inject != self.inject_eps:
                 if self.graph is not None:
