@@ -79,11 +79,15 @@ def test_eval_mode_gradients_are_refused():
     import vae_amd
     m, g = _model("mnist_lat15")
     m.eval()
-    with pytest.raises(vae_amd._lib.VaeAmdError, match="eval-mode BatchNorm"):
-        m(g["x"].to(DEV), eps=g["eps0"].to(DEV))
+    # the forward itself is legal with grad enabled (model.eval(); model(x) in a notebook) and equals the no_grad one ...
+    x_rec, mu, logvar = m(g["x"].to(DEV), eps=g["eps0"].to(DEV))
+    assert x_rec.requires_grad and torch.isfinite(x_rec).all()
     with torch.no_grad():
-        x_rec, mu, logvar = m(g["x"].to(DEV), eps=g["eps0"].to(DEV))
-    assert torch.isfinite(x_rec).all()
+        x_rec2, mu2, logvar2 = m(g["x"].to(DEV), eps=g["eps0"].to(DEV))
+    assert torch.equal(x_rec.detach(), x_rec2) and torch.equal(mu.detach(), mu2)
+    # ... only a backward through its outputs is refused (the executor has no eval-mode BatchNorm gradient)
+    with pytest.raises(vae_amd._lib.VaeAmdError, match="eval-mode BatchNorm"):
+        (x_rec.sum() + mu.sum()).backward()
 
 
 @pytest.mark.parametrize("stem", ["mnist_lat15", "multiscale_c3_l60"])

@@ -214,6 +214,7 @@ struct LinWgArgs {
     int chunks_per_block;  // consecutive LW_BB-sample chunks handled by one workgroup
     int gx, gy, gz;        // workgroups of this layer: batch slices x 64-row tiles x 64-column tiles
     int first_block;       // of this layer in the flattened grid
+    int vec;               // rows of dY, Y and X are 16-byte aligned and N, K multiples of 4: dwordx4 staging
 };
 
 // The weight gradients of ALL Linear layers of a backward pass in one launch (they only have to be done
@@ -227,8 +228,8 @@ struct LinWgMulti {
 
 template <bool BF>
 __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
-    __shared__ float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+64)
-    __shared__ float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
+    __shared__ __attribute__((aligned(16))) float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+64)
+    __shared__ __attribute__((aligned(16))) float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
     int layer = 0;
 #pragma unroll
     for (int i = 1; i < LIN_WG_MAX_LAYERS; ++i)
@@ -250,8 +251,27 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     const int c_end = min(c_first + a.chunks_per_block, (a.B + LW_BB - 1) / LW_BB);
     const bool has_act = a.act != VAE_ACT_NONE;
     float vy[16], vyy[16], vx[16];
+    const bool vec = a.vec != 0;
     auto load_chunk = [&](int ch) {  // 64 rows x 64 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
         const int b0 = ch * LW_BB;
+        if (vec) {
+            // four float4 per tensor and thread, every load unconditional with a clamped address (a load under a branch
+            // is waited for on the spot); what lies past an edge is zeroed when it goes to LDS
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = tid + j * LIN_THREADS;  // 1024 = 64 rows x 16 float4
+                const int r = min(b0 + (e >> 4), a.B - 1), cn = min(n0 + ((e & 15) << 2), a.N - 4), ck = min(k0 + ((e & 15) << 2), a.K - 4);
+                const float4 y4 = *reinterpret_cast<const float4*>(a.dY + (int64_t)r * a.lddy + cn);
+                const float4 x4 = *reinterpret_cast<const float4*>(a.X + (int64_t)r * a.ldx + ck);
+                vy[4 * j] = y4.x; vy[4 * j + 1] = y4.y; vy[4 * j + 2] = y4.z; vy[4 * j + 3] = y4.w;
+                vx[4 * j] = x4.x; vx[4 * j + 1] = x4.y; vx[4 * j + 2] = x4.z; vx[4 * j + 3] = x4.w;
+                if (has_act) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(a.Y + (int64_t)r * a.ldy + cn);
+                    vyy[4 * j] = q4.x; vyy[4 * j + 1] = q4.y; vyy[4 * j + 2] = q4.z; vyy[4 * j + 3] = q4.w;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int e = tid + j * LIN_THREADS;  // 4096 = 64 x 64
@@ -273,6 +293,22 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     if (c_first < c_end) load_chunk(c_first);
     for (int ch = c_first; ch < c_end; ++ch) {
         __syncthreads();
+        if (vec) {
+            const int b0 = ch * LW_BB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = tid + j * LIN_THREADS, r = e >> 4, c4 = (e & 15) << 2;
+                const bool rok = b0 + r < a.B, yok = rok && n0 + c4 < a.N, xok = rok && k0 + c4 < a.K;
+                float4 y4, x4;
+                y4.x = yok ? (has_act ? vy[4 * j] * act_grad_from_out(vyy[4 * j], a.act, a.slope) : vy[4 * j]) : 0.f;
+                y4.y = yok ? (has_act ? vy[4 * j + 1] * act_grad_from_out(vyy[4 * j + 1], a.act, a.slope) : vy[4 * j + 1]) : 0.f;
+                y4.z = yok ? (has_act ? vy[4 * j + 2] * act_grad_from_out(vyy[4 * j + 2], a.act, a.slope) : vy[4 * j + 2]) : 0.f;
+                y4.w = yok ? (has_act ? vy[4 * j + 3] * act_grad_from_out(vyy[4 * j + 3], a.act, a.slope) : vy[4 * j + 3]) : 0.f;
+                x4.x = xok ? vx[4 * j] : 0.f; x4.y = xok ? vx[4 * j + 1] : 0.f; x4.z = xok ? vx[4 * j + 2] : 0.f; x4.w = xok ? vx[4 * j + 3] : 0.f;
+                *reinterpret_cast<float4*>(Ys + r * LW_YS + c4) = y4;
+                *reinterpret_cast<float4*>(Xs + r * LW_XS + c4) = x4;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int e = tid + j * LIN_THREADS;
@@ -282,6 +318,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
         for (int j = 0; j < 16; ++j) {
             const int e = tid + j * LIN_THREADS;
             Xs[(e >> 6) * LW_XS + (e & 63)] = vx[j];
+        }
         }
         __syncthreads();
         if (ch + 1 < c_end) load_chunk(ch + 1);

@@ -1634,19 +1634,23 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_be_k(SqDesc d, int i) {
 }
 
 // ---- gradient rows -> flat GRAD buffer -----------------------------------------------------------------------
-// grad[j] = sum over the workgroup rows, fixed order (16 slices striding over the rows, then a 16-term sum).
+// grad[j] = sum over the workgroup rows, fixed order (8 slices striding over the rows, then an 8-term sum).  A
+// workgroup covers SQR_COLS = 32 columns: a wave instruction then reads whole 128-byte lines of two rows (with 16
+// columns every load left half of its line unused and the launch fetched 2.5 x the rows' bytes).
+#define SQR_COLS 32
+#define SQR_SLICES (256 / SQR_COLS)
 __global__ __launch_bounds__(256) void sq_reduce_k(const float* __restrict__ part, float* __restrict__ grad, int64_t nflat,
                                                    int rows) {
-    __shared__ float red[16][17];
-    const int jj = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int64_t j = (int64_t)blockIdx.x * 16 + jj;
+    __shared__ float red[SQR_SLICES][SQR_COLS + 1];
+    const int jj = threadIdx.x & (SQR_COLS - 1), slice = threadIdx.x / SQR_COLS;
+    const int64_t j = (int64_t)blockIdx.x * SQR_COLS + jj;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (j < nflat) {
         int b = slice;
-        for (; b + 240 < rows; b += 256) {  // sixteen rows in one latency round (same order of additions as below)
+        for (; b + 15 * SQR_SLICES < rows; b += 16 * SQR_SLICES) {  // sixteen rows in one latency round
             float x[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = part[(int64_t)(b + 16 * q) * nflat + j];
+            for (int q = 0; q < 16; ++q) x[q] = part[(int64_t)(b + SQR_SLICES * q) * nflat + j];
 #pragma unroll
             for (int q = 0; q < 16; q += 4) {
                 t0 += x[q];
@@ -1655,19 +1659,19 @@ __global__ __launch_bounds__(256) void sq_reduce_k(const float* __restrict__ par
                 t3 += x[q + 3];
             }
         }
-        for (; b + 48 < rows; b += 64) {
+        for (; b + 3 * SQR_SLICES < rows; b += 4 * SQR_SLICES) {
             t0 += part[(int64_t)b * nflat + j];
-            t1 += part[(int64_t)(b + 16) * nflat + j];
-            t2 += part[(int64_t)(b + 32) * nflat + j];
-            t3 += part[(int64_t)(b + 48) * nflat + j];
+            t1 += part[(int64_t)(b + SQR_SLICES) * nflat + j];
+            t2 += part[(int64_t)(b + 2 * SQR_SLICES) * nflat + j];
+            t3 += part[(int64_t)(b + 3 * SQR_SLICES) * nflat + j];
         }
-        for (; b < rows; b += 16) t0 += part[(int64_t)b * nflat + j];
+        for (; b < rows; b += SQR_SLICES) t0 += part[(int64_t)b * nflat + j];
     }
     red[slice][jj] = (t0 + t1) + (t2 + t3);
     sq_bar();
     if (slice != 0 || j >= nflat) return;
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sum += red[k][jj];
+    for (int k = 0; k < SQR_SLICES; ++k) sum += red[k][jj];
     grad[j] = sum;
 }

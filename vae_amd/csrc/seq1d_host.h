@@ -443,7 +443,7 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* t
         VAE_LAUNCH_CHECK("sq_be_k");
     }
     sq_mark(tm, c.s, "reduce", (double)d.nflat * (d.grid + 1));
-    hipLaunchKernelGGL(sq_reduce_k, dim3((unsigned)ceil_div64(d.nflat, 16)), dim3(256), 0, c.s, d.part, grad, d.nflat, d.grid);
+    hipLaunchKernelGGL(sq_reduce_k, dim3((unsigned)ceil_div64(d.nflat, SQR_COLS)), dim3(256), 0, c.s, d.part, grad, d.nflat, d.grid);
     VAE_LAUNCH_CHECK("sq_reduce_k");
     return VAE_OK;
 }

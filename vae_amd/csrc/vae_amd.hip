@@ -1598,7 +1598,8 @@ static LinWgPlan lin_wgrad_plan(int B, int N, int K) {
     LinWgPlan p;
     const int tiles = ((N + LW_BN - 1) / LW_BN) * ((K + 63) / 64);
     const int nch = (B + LW_BB - 1) / LW_BB;
-    int gx = (512 + tiles - 1) / tiles;
+    static const int target = [] { const char* e = getenv("VAE_LINWG_TARGET"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 512; }();
+    int gx = (target + tiles - 1) / tiles;
     if (gx > nch) gx = nch;
     p.chunks_per_block = (nch + gx - 1) / gx;
     p.gx = (nch + p.chunks_per_block - 1) / p.chunks_per_block;
@@ -1611,6 +1612,9 @@ extern "C" int64_t vae_linear_wgrad_partial_floats(const vae_op* op, int B) {
     return (int64_t)lin_wgrad_plan(B, N, K).gx * ((int64_t)N * K + N);
 }
 
+// (Measured and dropped in round 3: this launch on a side stream / graph branch beside the encoder's convolution
+// backward, forked behind the Linear run's input gradients and joined before wgrad_finalize_k: 0.508 -> 0.513 ms/step.
+// Like the conv weight gradients in round 1, kernels that each fill the CUs only take turns.)
 static int flush_linear_wgrads(const Ctx& c) {
     LinWgMulti& m = c.lin_wg;
     if (m.n == 0) return VAE_OK;
@@ -1707,6 +1711,11 @@ static int linear_backward(const Ctx& c, const vae_op& op, const vae_op* sib = n
     const LinWgPlan lp = lin_wgrad_plan(c.B, N, K);
     wa.chunks_per_block = lp.chunks_per_block;
     wa.gx = lp.gx; wa.gy = lp.gy; wa.gz = lp.gz;
+    {
+        auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        wa.vec = (N % 4 == 0 && K % 4 == 0 && N >= 4 && K >= 4 && lddy % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && al16(dy) && al16(y) &&
+                  al16(x)) ? 1 : 0;
+    }
     if (op.r[10] < 0) VAE_FAIL(VAE_EINVAL, "linear: backward needs the op's weight-gradient partial region (r[10], vae_linear_wgrad_partial_floats)");
     const int64_t prow = (int64_t)N * K + N;
     wa.part = resolve(c, op.r[10], lp.gx * prow, "linear.wgrad_partials", &ok);

@@ -148,11 +148,18 @@ class HipModule(nn.Module):
             prog.forward(work, flat, sflat, ext, self.training)
             return {n: prog.view(work, *prog.outputs[n]) for n in names}
         if not self.training and self._bn_holders():
-            # the backward kernels implement the train-mode BatchNorm gradient (batch-statistic terms included);
-            # eval-mode BatchNorm has the affine-only gradient, which is not built: refuse instead of returning
-            # silently wrong gradients (the reference only runs eval under torch.no_grad(), train.py:77-79)
-            raise L.VaeAmdError("vae_amd: gradients through an eval-mode BatchNorm are not supported; call the model "
-                                "under torch.no_grad() in eval mode (as train.py:test does) or switch to .train()")
+            # The backward kernels implement the train-mode BatchNorm gradient (batch-statistic terms included);
+            # eval-mode BatchNorm has the affine-only gradient, which is not built.  model.eval(); model(x) without
+            # torch.no_grad() is legal and common (the reference itself only runs eval under no_grad, train.py:77-79),
+            # so the forward runs (forward-only program) and only a backward() THROUGH its outputs raises.
+            with torch.no_grad():
+                prog = self.compiled(B, False)
+                work = prog.new_workspace(x0.device)
+                prog.forward(work, flat, sflat, ext, False)
+                outs = [prog.view(work, *prog.outputs[n]) for n in prog.outputs]
+            if any(p.requires_grad for p in self._param_list):
+                outs = _EvalOutputsFn.apply(self._param_list[0], *outs)
+            return dict(zip(list(prog.outputs), outs))
         outs = _ProgramFn.apply(self, prog, len(inputs), *inputs, *self._param_list)
         return dict(zip(names, outs))
 
@@ -163,6 +170,19 @@ def storage_alias(t):
     doing so through the original tensor would bump the version the output views share."""
     return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape,
                                                                   t.stride())
+
+
+class _EvalOutputsFn(torch.autograd.Function):
+    """Marks eval-mode outputs as differentiable in name only: backward through them is refused (see run_program)."""
+
+    @staticmethod
+    def forward(ctx, anchor, *outs):
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        raise L.VaeAmdError("vae_amd: gradients through an eval-mode BatchNorm are not supported; call the model "
+                            "under torch.no_grad() in eval mode (as train.py:test does) or switch to .train()")
 
 
 class _ProgramFn(torch.autograd.Function):
