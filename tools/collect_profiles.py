@@ -19,4 +19,10 @@ for m in models:
         out = subprocess.run([sys.executable, f"{root}/tools/pmc_summary.py", os.path.dirname(f[0]), os.path.dirname(w[0])],
                              capture_output=True, text=True, check=True).stdout
         open(f"{root}/profiles/{name}", "w").write(out)
-    print(m, bool(st), bool(f and w))
+    sq = glob.glob(f"{root}/gpurun_out/{tag}_{m}_sq/**/pmc_counter_collection.csv", recursive=True)
+    if sq:
+        name = f"{tag}_sq_counters.csv" if m == "mnist" else f"{tag}_{m}_sq_counters.csv"
+        out = subprocess.run([sys.executable, f"{root}/tools/sq_summary.py", os.path.dirname(sq[0])],
+                             capture_output=True, text=True, check=True).stdout
+        open(f"{root}/profiles/{name}", "w").write(out)
+    print(m, bool(st), bool(f and w), bool(sq))

@@ -19,5 +19,10 @@ for M in $MODELS; do
     rm -rf "$d"
     timeout -s KILL 180 rocprofv3 --pmc $c --kernel-trace -d "$d" -o pmc --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-strong-ref --roofline-iters 1 > "$d.log" 2>&1 || { tail -5 "$d.log"; exit 1; }
   done
+  if [ $M = mnist ] || [ $M = wide ]; then   # SQ counters (one pass holds at most 8 of them): tools/sq_summary.py reads the result
+    d=$R/gpurun_out/${TAG}_${M}_sq
+    rm -rf "$d"
+    timeout -s KILL 180 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace -d "$d" -o pmc --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-strong-ref --roofline-iters 1 > "$d.log" 2>&1 || { tail -5 "$d.log"; exit 1; }
+  fi
   echo "$M done"
 done
