@@ -87,7 +87,10 @@ def run_gpu(stem, family, kw):
     m.load_state_dict(sub(g, "sd/"))
     m.to(dev).train()
     opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
-    st = DataParallelTrainStep(m, opt, hi - lo, dev)
+    # mode "gpu": the path the step picks by itself (1-D families: the whole-model seq1d path with its rank-row
+    # exchange between the phases); "gpu_layers": the per-layer program
+    st = DataParallelTrainStep(m, opt, hi - lo, dev, allow_seq1d=(MODE != "gpu_layers"))
+    assert bool(getattr(st.prog, "seq1d", False)) == (family != "mnist" and MODE != "gpu_layers"), (family, MODE)
     st.inject_eps = True
     x = g["x"][lo:hi].to(dev)
     for step in range(3):
@@ -129,8 +132,13 @@ def run_native_fail(bad_rank):
     assert lib.vae_dp_world() == 0
 
 
+MODE = "gpu"
+
+
 def main():
+    global MODE
     mode, stem = sys.argv[1], sys.argv[2]
+    MODE = mode
     dist.init_process_group("gloo")
     try:
         if mode == "native_fail":

@@ -57,11 +57,20 @@ def test_native_init_failure_is_agreed_on_by_every_rank(bad_rank):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stem", ["mnist_lat15", "tcvae_c3_n3_l60_fk21", "multiscale_c3_l60"])
-def test_dp_hip_path_two_ranks(stem):
+@pytest.mark.parametrize("stem,mode", [("mnist_lat15", "gpu"), ("tcvae_c3_n3_l60_fk21", "gpu"), ("multiscale_c3_l60", "gpu"),
+                                       ("tcvae_c3_n3_l60_fk21", "gpu_layers"), ("multiscale_c3_l60", "gpu_layers")])
+def test_dp_hip_path_two_ranks(stem, mode):
     """DataParallelTrainStep (HIP kernels, SyncBN hook, gradient all-reduce) on two ranks sharing the GPU
-    reproduces the golden 3-step trajectory of the global batch."""
-    _run_world("gpu", stem)
+    reproduces the golden 3-step trajectory of the global batch.  The 1-D families run twice: on the whole-model
+    seq1d path (statistics rows of the ranks exchanged between the phases) and on the per-layer program."""
+    _run_world(mode, stem)
+
+
+@pytest.mark.gpu
+def test_dp_seq1d_three_uneven_ranks():
+    """Three ranks with shards of 6 / 5 / 5 samples on the whole-model 1-D path: the backward prologue takes the
+    global count per channel from the ranks' rows, not from world x its own batch."""
+    _run_world("gpu", "multiscale_c3_l60", world=3)
 
 
 @pytest.mark.gpu

@@ -57,6 +57,10 @@ struct SqLayer {
     float* g;            // [B][cout][lout] gradient w.r.t. the BatchNorm output (w.r.t. y when !has_bn)
     float* fstat;        // [3][cout][grid] per-workgroup {n, mean, M2}
     float* bstat;        // [2][cout][grid] per-workgroup {sum g, sum g*xhat}
+    // data parallel (SqDesc.world > 1): one row per rank of this layer's statistics inside SqDesc.gath, gathered
+    // between the phases: forward {n, mean, M2}[cout] at gath[fg_off + r*fg_stride], backward {sum g, sum g*xhat}[cout]
+    // + n at gath[bg_off + r*bg_stride]
+    int fg_off, fg_stride, bg_off, bg_stride;
     int64_t w_off, b_off, ga_off, be_off;  // float offsets of the gradients in the flat GRAD buffer / a partial row
 };
 struct SqHead {
@@ -67,6 +71,8 @@ struct SqHead {
 struct SqDesc {
     int B, SB, grid, nchunks, training;
     int prune;       // eval forward without a criterion: the decoder is evaluated at time index 0 only (sq_fh_k)
+    int world, rank; // data parallel: BatchNorm statistics over the batch of every rank (rows gathered between phases)
+    float* gath;     // the ranks' rows (SqLayer.fg_off / bg_off)
     int NE, ND, nenc, lat, lat_total;
     int C, L;        // input window (C, L)
     float slope;     // LeakyReLU slope of every conv / convT (0 = ReLU)
@@ -435,9 +441,13 @@ struct SqBnRef {  // the fields of a layer its BatchNorm helpers need (kernel ar
     int cout, lout;
     float bn_eps, bn_mom;
     int64_t ga_off, be_off;
+    const float *fgath, *bgath;  // world > 1: the gathered rows of the ranks (strides fgs / bgs floats)
+    int world, rank, fgs, bgs;
 };
-__device__ __forceinline__ SqBnRef sq_bnref(const SqLayer& y) {
+__device__ __forceinline__ SqBnRef sq_bnref(const SqLayer& y, const float* gath, int world, int rank) {
     SqBnRef r;
+    r.world = world; r.rank = rank; r.fgs = y.fg_stride; r.bgs = y.bg_stride;
+    r.fgath = gath + y.fg_off; r.bgath = gath + y.bg_off;
     r.fstat = y.fstat; r.bstat = y.bstat; r.gamma = y.gamma; r.beta = y.beta; r.rmean = y.rmean; r.rvar = y.rvar;
     r.save = y.save; r.cout = y.cout; r.lout = y.lout; r.bn_eps = y.bn_eps; r.bn_mom = y.bn_mom; r.ga_off = y.ga_off;
     r.be_off = y.be_off;
@@ -446,7 +456,9 @@ __device__ __forceinline__ SqBnRef sq_bnref(const SqLayer& y) {
 template <int NL>
 __device__ __forceinline__ void sq_bn_prepare_f(const SqBnRef& P0, const SqBnRef& P1, lds_f* coef0, lds_f* coef1, int training) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gl = lane & 15;
-    const int rows = gridDim.x;
+    // data parallel: the rows are the ranks' merged rows (sq_rank_rows_k + all-gather), [rank][3][C]
+    const bool dp = P0.world > 1;
+    const int rows = dp ? P0.world : gridDim.x;
     const int Cmax = NL == 2 ? max(P0.cout, P1.cout) : P0.cout;
     for (int c0 = wid * 4; c0 < Cmax; c0 += SQ_WAVES * 4) {
         const int c = c0 + (lane >> 4);
@@ -461,14 +473,15 @@ __device__ __forceinline__ void sq_bn_prepare_f(const SqBnRef& P0, const SqBnRef
         if (training) {
             // rows % 4 == 0 (any batch that fills the grid): 16-byte loads, a quarter of the load instructions (the
             // texture-address unit takes 16 cycles per wave instruction whatever its width)
-            const bool vec = (rows & 3) == 0;
+            const bool vec = !dp && (rows & 3) == 0;
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const SqBnRef& P = l == 0 ? P0 : P1;
                 const int C = P.cout, cc = c < C ? c : C - 1;
-                gl_cf* rn = (gl_cf*)(P.fstat + (int64_t)cc * rows);
-                gl_cf* rm = (gl_cf*)(P.fstat + (int64_t)(C + cc) * rows);
-                gl_cf* rq = (gl_cf*)(P.fstat + (int64_t)(2 * C + cc) * rows);
+                gl_cf* rn = (gl_cf*)(dp ? P.fgath + cc : P.fstat + (int64_t)cc * rows);
+                gl_cf* rm = (gl_cf*)(dp ? P.fgath + C + cc : P.fstat + (int64_t)(C + cc) * rows);
+                gl_cf* rq = (gl_cf*)(dp ? P.fgath + 2 * C + cc : P.fstat + (int64_t)(2 * C + cc) * rows);
+                const int rs = dp ? P.fgs : 1;
                 pv[l] = rm[0];
                 if (vec) {
                     const int r4n = rows >> 2;
@@ -490,7 +503,7 @@ __device__ __forceinline__ void sq_bn_prepare_f(const SqBnRef& P0, const SqBnRef
                     for (int j = 0; j < 16; ++j) {
                         const int r = gl + 16 * j;
                         const bool ok = r < rows;
-                        const int rr = ok ? r : 0;
+                        const int rr = ok ? r * rs : 0;
                         const float a = rn[rr], b = rm[rr], q = rq[rr];
                         vn[l][j] = ok ? a : 0.f; vm[l][j] = b; vq[l][j] = ok ? q : 0.f;
                     }
@@ -535,8 +548,9 @@ __device__ __forceinline__ void sq_bn_prepare_f(const SqBnRef& P0, const SqBnRef
         }
     }
 }
-#define sq_bn_prepare(P, coef, training) sq_bn_prepare_f<1>(sq_bnref(P), sq_bnref(P), SQL(coef), SQL(coef), training)
-#define sq_bn_prepare2(P0, c0, P1, c1, training) sq_bn_prepare_f<2>(sq_bnref(P0), sq_bnref(P1), SQL(c0), SQL(c1), training)
+#define SQ_BNREF(P) sq_bnref(P, d.gath, d.world, d.rank)
+#define sq_bn_prepare(P, coef, training) sq_bn_prepare_f<1>(SQ_BNREF(P), SQ_BNREF(P), SQL(coef), SQL(coef), training)
+#define sq_bn_prepare2(P0, c0, P1, c1, training) sq_bn_prepare_f<2>(SQ_BNREF(P0), SQ_BNREF(P1), SQL(c0), SQL(c1), training)
 
 // Backward prologue for the BatchNorm of NL layers: coef[4C..6C) = {m1 = sum g / n, m2 = sum g*xhat / n} from the rows
 // the previous phase left (coef[0..4C), the save block, is copied by the caller's LDS-DMA).  Every workgroup puts
@@ -544,18 +558,34 @@ __device__ __forceinline__ void sq_bn_prepare_f(const SqBnRef& P0, const SqBnRef
 template <int NL>
 __device__ __forceinline__ void sq_bn_bwd_prepare_f(const SqBnRef& L0, const SqBnRef& L1, lds_f* coef0, lds_f* coef1, float* prow, int B) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gl = lane & 15;
-    const int rows = gridDim.x;
+    // data parallel: rows = the ranks' sums [rank][2C + 4] (the count of the rank's values per channel at [2C]);
+    // dx needs the means over the global batch, dgamma / dbeta stay this rank's sums (the gradient all-reduce adds them)
+    const bool dp = L0.world > 1;
+    const int rows = dp ? L0.world : gridDim.x;
     const int Cmax = NL == 2 ? max(L0.cout, L1.cout) : L0.cout;
     for (int c0 = wid * 4; c0 < Cmax; c0 += SQ_WAVES * 4) {
         const int c = c0 + (lane >> 4);
-        float v1[NL][16], v2[NL][16];
-        const bool vec = (rows & 3) == 0;
+        float v1[NL][16], v2[NL][16], vc[NL], own1[NL], own2[NL];
+        const bool vec = !dp && (rows & 3) == 0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const SqBnRef& Lr = l == 0 ? L0 : L1;
             const int C = Lr.cout, cc = c < C ? c : C - 1;
-            gl_cf* r1 = (gl_cf*)(Lr.bstat + (int64_t)cc * rows);
-            gl_cf* r2 = (gl_cf*)(Lr.bstat + (int64_t)(C + cc) * rows);
+            gl_cf* r1 = (gl_cf*)(dp ? Lr.bgath + cc : Lr.bstat + (int64_t)cc * rows);
+            gl_cf* r2 = (gl_cf*)(dp ? Lr.bgath + C + cc : Lr.bstat + (int64_t)(C + cc) * rows);
+            const int rs = dp ? Lr.bgs : 1;
+            vc[l] = 0.f; own1[l] = own2[l] = 0.f;
+            if (dp) {
+                gl_cf* rc = (gl_cf*)(Lr.bgath + 2 * C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // world <= 64
+                    const int r = gl + 16 * j;
+                    const float n = rc[r < rows ? r * rs : 0];
+                    vc[l] += r < rows ? n : 0.f;
+                }
+                own1[l] = r1[Lr.rank * rs];
+                own2[l] = r2[Lr.rank * rs];
+            }
             if (vec) {
                 const int r4n = rows >> 2;
 #pragma unroll
@@ -572,7 +602,7 @@ __device__ __forceinline__ void sq_bn_bwd_prepare_f(const SqBnRef& L0, const SqB
                 for (int j = 0; j < 16; ++j) {
                     const int r = gl + 16 * j;
                     const bool ok = r < rows;
-                    const int rr = ok ? r : 0;
+                    const int rr = ok ? r * rs : 0;
                     const float a = r1[rr], b = r2[rr];
                     v1[l][j] = ok ? a : 0.f;
                     v2[l][j] = ok ? b : 0.f;
@@ -589,12 +619,14 @@ __device__ __forceinline__ void sq_bn_bwd_prepare_f(const SqBnRef& L0, const SqB
             for (int j = 0; j < 16; ++j) { s1 += v1[l][j]; s2 += v2[l][j]; }
             s1 = sq_row_sum(s1);
             s2 = sq_row_sum(s2);
+            float ntot = (float)B * (float)Lr.lout;
+            if (dp) ntot = sq_row_sum(vc[l]);
             if (gl == 0 && c < C) {
-                const float ninv = 1.f / ((float)B * (float)Lr.lout);
+                const float ninv = 1.f / ntot;
                 coef[4 * C + c] = s1 * ninv;
                 coef[5 * C + c] = s2 * ninv;
-                prow[Lr.be_off + c] = blockIdx.x == 0 ? s1 : 0.f;
-                prow[Lr.ga_off + c] = blockIdx.x == 0 ? s2 : 0.f;
+                prow[Lr.be_off + c] = blockIdx.x == 0 ? (dp ? own1[l] : s1) : 0.f;
+                prow[Lr.ga_off + c] = blockIdx.x == 0 ? (dp ? own2[l] : s2) : 0.f;
             }
         }
     }
@@ -607,8 +639,8 @@ __device__ __forceinline__ void sq_bn_bwd_prepare_f(const SqBnRef& L0, const SqB
             prow[Lr.be_off + c] = prow[Lr.ga_off + c] = 0.f;
     }
 }
-#define sq_bn_bwd_prepare(Lr, coef, prow, B) sq_bn_bwd_prepare_f<1>(sq_bnref(Lr), sq_bnref(Lr), SQL(coef), SQL(coef), prow, B)
-#define sq_bn_bwd_prepare2(L0, c0, L1, c1, prow, B) sq_bn_bwd_prepare_f<2>(sq_bnref(L0), sq_bnref(L1), SQL(c0), SQL(c1), prow, B)
+#define sq_bn_bwd_prepare(Lr, coef, prow, B) sq_bn_bwd_prepare_f<1>(SQ_BNREF(Lr), SQ_BNREF(Lr), SQL(coef), SQL(coef), prow, B)
+#define sq_bn_bwd_prepare2(L0, c0, L1, c1, prow, B) sq_bn_bwd_prepare_f<2>(SQ_BNREF(L0), SQ_BNREF(L1), SQL(c0), SQL(c1), prow, B)
 
 // ---- staging -----------------------------------------------------------------------------------------------
 // Every global load of a stage is ISSUED before the first one is waited for: contiguous copies go global -> LDS by
@@ -1631,6 +1663,60 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_be_k(SqDesc d, int i) {
         _Pragma("unroll") for (int e = 0; e < NENC; ++e) sq_write_rows(d.enc[e][i - 1].bstat, wst[e], 2, d.enc[e][i].cin);
     sq_blk_flush(blk, smem, prow);
     SQ_TPRINT("be: setup | stage gemms out+bsums:", 5);
+}
+
+// ---- data parallel: this rank's statistics rows -> ONE row (before the all-gather between two phases) -----------
+// forward (nq = 3): Chan merge of the workgroups' {n, mean, M2} rows around the pivot mean(row 0), as sq_bn_prepare_f
+// does; backward (nq = 2): plain sums of {sum g, sum g*xhat} and the rank's count of values per channel behind them.
+// One wave per channel, lane l takes the rows l, l + 64, ...; the wave sum runs in a fixed order.
+struct SqRankRows {
+    const float* stat[SQ_MAXENC];  // [nq][C][rows]
+    float* out[SQ_MAXENC];         // forward [3][C], backward [2][C] + {n}
+    int C[SQ_MAXENC];
+    float n_local[SQ_MAXENC];
+    int rows, nq;
+};
+__device__ __forceinline__ float sq_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void sq_rank_rows_k(SqRankRows a) {
+    const int l = blockIdx.y, lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float* stat = l == 0 ? a.stat[0] : a.stat[SQ_MAXENC - 1];
+    float* out = l == 0 ? a.out[0] : a.out[SQ_MAXENC - 1];
+    const int C = l == 0 ? a.C[0] : a.C[SQ_MAXENC - 1], rows = a.rows;
+    if (c >= C) return;  // (wave-uniform)
+    if (a.nq == 3) {
+        const float pivot = stat[(int64_t)(C + c) * rows];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int r = lane; r < rows; r += 64) {
+            const float n = stat[(int64_t)c * rows + r], dm = stat[(int64_t)(C + c) * rows + r] - pivot;
+            const float q = stat[(int64_t)(2 * C + c) * rows + r];
+            s0 += n;
+            s1 = fmaf(n, dm, s1);
+            s2 += fmaf(n * dm, dm, q);
+        }
+        s0 = sq_wave_sum(s0); s1 = sq_wave_sum(s1); s2 = sq_wave_sum(s2);
+        if (lane == 0) {
+            const float dmean = s1 / s0;
+            out[c] = s0;
+            out[C + c] = pivot + dmean;
+            out[2 * C + c] = fmaxf(s2 - s1 * dmean, 0.f);
+        }
+    } else {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = lane; r < rows; r += 64) {
+            s1 += stat[(int64_t)c * rows + r];
+            s2 += stat[(int64_t)(C + c) * rows + r];
+        }
+        s1 = sq_wave_sum(s1); s2 = sq_wave_sum(s2);
+        if (lane == 0) {
+            out[c] = s1;
+            out[C + c] = s2;
+            if (c == 0) out[2 * C] = l == 0 ? a.n_local[0] : a.n_local[SQ_MAXENC - 1];
+        }
+    }
 }
 
 // ---- gradient rows -> flat GRAD buffer -----------------------------------------------------------------------

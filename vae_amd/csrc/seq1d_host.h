@@ -182,7 +182,13 @@ static int64_t sq_scratch_floats(const SqDesc& d, int64_t nflat) {
     for (int e = 0; e < d.nenc; ++e)
         for (int i = 0; i < d.NE; ++i) n += (int64_t)5 * d.enc[e][i].cout * d.grid;
     for (int j = 0; j < d.ND; ++j) n += (int64_t)5 * d.dec[j].cout * d.grid;
-    return n + (int64_t)d.grid * nflat + 64;
+    // + the ranks' gathered statistics rows of a data-parallel step (sized for any world: the collective may be
+    // installed after the program was built)
+    int64_t g = 0;
+    for (int e = 0; e < d.nenc; ++e)
+        for (int i = 0; i < d.NE; ++i) g += 5 * d.enc[e][i].cout + 4;
+    for (int j = 0; j < d.ND; ++j) g += 5 * d.dec[j].cout + 4;
+    return n + (int64_t)d.grid * nflat + 64 + g * VAE_MAX_WORLD;
 }
 
 static bool sq_enabled() { return sq_env_int("VAE_AMD_SEQ1D", 1) != 0; }
@@ -245,6 +251,31 @@ static int sq_bind(const Ctx& c, const vae_op* ops, SqProgram* p, int training, 
     }
     for (int j = 0; j < d.ND; ++j) bind_layer(d.dec[j], ops[p->dec_conv[j]], p->dec_bn[j] >= 0 ? &ops[p->dec_bn[j]] : nullptr);
     d.part = sp;
+    {   // data parallel: per BatchNorm boundary (layer i of every encoder; a decoder layer) [world][floats of the boundary]
+        d.world = training ? g_world : 1;
+        d.rank = training ? g_rank : 0;
+        d.gath = sp + (int64_t)d.grid * nflat + 64;
+        int64_t off = 0;
+        auto boundary = [&](SqLayer** ys, int n) {
+            int fs = 0, bs = 0;
+            for (int k = 0; k < n; ++k) { fs += 3 * ys[k]->cout; bs += 2 * ys[k]->cout + 4; }
+            int fo = 0, bo = 0;
+            for (int k = 0; k < n; ++k) {
+                SqLayer& y = *ys[k];
+                y.fg_stride = fs; y.bg_stride = bs;
+                y.fg_off = (int)(off + fo);
+                y.bg_off = (int)(off + (int64_t)fs * VAE_MAX_WORLD + bo);
+                fo += 3 * y.cout; bo += 2 * y.cout + 4;
+            }
+            off += (int64_t)(fs + bs) * VAE_MAX_WORLD;
+        };
+        for (int i = 0; i < d.NE; ++i) {
+            SqLayer* ys[SQ_MAXENC];
+            for (int e = 0; e < d.nenc; ++e) ys[e] = &d.enc[e][i];
+            boundary(ys, d.nenc);
+        }
+        for (int j = 0; j < d.ND; ++j) { SqLayer* ys[1] = {&d.dec[j]}; boundary(ys, 1); }
+    }
     const vae_op &rp = ops[p->reparam], &dl = ops[p->lin], &sl = ops[p->slice0];
     const int c0 = d.dec[0].cin;
     const int64_t nlat = (int64_t)B * d.lat_total;
@@ -295,6 +326,8 @@ static int sq_bind(const Ctx& c, const vae_op* ops, SqProgram* p, int training, 
 // dynamic LDS beyond 64 KiB has to be granted per kernel, once per device
 static int sq_grant_lds() {
     static bool done[64];
+    static std::mutex mu;   // two host threads may run programs on two devices at once
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     VAE_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) VAE_FAIL(VAE_EINVAL, "device index %d out of range", dev);
@@ -314,10 +347,10 @@ static int sq_grant_lds() {
     return VAE_OK;
 }
 
-// true: the op array is a seq1d program (matched, scratch attached, single GPU)
+// true: the op array is a seq1d program (matched, scratch attached)
 static bool sq_use(const vae_op* ops, int n_ops, int B, SqProgram* p) {
     // (fp32 only: under the bf16 compute dtype the program runs op by op on the kernels that have bf16 instances)
-    if (n_ops < 6 || ops[0].r[11] < 0 || g_world > 1 || g_bf16 || !sq_enabled()) return false;
+    if (n_ops < 6 || ops[0].r[11] < 0 || g_bf16 || !sq_enabled()) return false;
     return sq_match(ops, n_ops, p) && sq_plan(p->d, B);
 }
 
@@ -335,10 +368,10 @@ static thread_local int sq_tl_nenc = 1;  // (for the kernel names of vae_time_st
 static void sq_mark(SqTimer* tm, hipStream_t s, const char* tag, double floats) {
     if (vae_tl_timer != nullptr) {  // vae_time_step: the launch that follows carries these bytes and the phase tag
         VAE_TBYTES(4.0 * floats);
-        const char* kn = tag[0] == 'r' ? "sq_reduce_k" : tag[0] == 'e' ? "elbo_finalize_k" :
+        const char* kn = tag[0] == 'r' ? "sq_reduce_k" : tag[0] == 'e' ? "elbo_finalize_k" : tag[0] == 'x' ? "sq_rank_rows_k" :
                          tag[1] == 'e' ? (tag[0] == 'f' ? "sq_fe_k" : "sq_be_k") : tag[1] == 'h' ? (tag[0] == 'f' ? "sq_fh_k" : "sq_bh_k") :
                                          (tag[0] == 'f' ? "sq_fd_k" : "sq_bd_k");
-        if (tag[0] != 'r' && tag[0] != 'e' && tag[1] != 'd') VAE_TNAME("%s<%d> (phase %s)", kn, sq_tl_nenc, tag);
+        if (tag[0] != 'r' && tag[0] != 'e' && tag[0] != 'x' && tag[1] != 'd') VAE_TNAME("%s<%d> (phase %s)", kn, sq_tl_nenc, tag);
         else VAE_TNAME("%s (phase %s)", kn, tag);
     }
     if (tm == nullptr || tm->n >= SQ_MAX_MARKS) return;
@@ -348,6 +381,44 @@ static void sq_mark(SqTimer* tm, hipStream_t s, const char* tag, double floats) 
     ++tm->n;
 }
 static double sq_layer_w(const SqLayer& y) { return (double)y.cin * y.cout * y.k + 3.0 * y.cout; }
+
+// Data parallel: the statistics rows that the phase just enqueued leaves for n layers (one BatchNorm boundary) become
+// one row per rank (sq_rank_rows_k) and are all-gathered in place through the collective hook; the next phase's
+// prologue merges the `world` rows.  backward: the rows of the backward sums.
+static int sq_exchange(const Ctx& c, const SqDesc& d, const SqLayer* const* ys, int n, bool backward, SqTimer* tm, const char* tag) {
+    if (d.world <= 1) return VAE_OK;
+    if (g_allgather == nullptr) VAE_FAIL(VAE_EINVAL, "seq1d: world %d without a collective hook", d.world);
+    SqRankRows a;
+    memset(&a, 0, sizeof(a));
+    int Cmax = 0;
+    for (int k = 0; k < n; ++k) {
+        const SqLayer& y = *ys[k];
+        const int slot = k == 0 ? 0 : SQ_MAXENC - 1;
+        a.stat[slot] = backward ? y.bstat : y.fstat;
+        a.out[slot] = d.gath + (backward ? y.bg_off + (int64_t)d.rank * y.bg_stride : y.fg_off + (int64_t)d.rank * y.fg_stride);
+        a.C[slot] = y.cout;
+        a.n_local[slot] = (float)d.B * (float)y.lout;
+        Cmax = y.cout > Cmax ? y.cout : Cmax;
+    }
+    a.rows = d.grid; a.nq = backward ? 2 : 3;
+    const SqLayer& y0 = *ys[0];
+    const int64_t stride = backward ? y0.bg_stride : y0.fg_stride;
+    sq_mark(tm, c.s, tag, (double)(a.nq * d.grid + a.nq) * Cmax * n);
+    hipLaunchKernelGGL(sq_rank_rows_k, dim3((Cmax + 3) / 4, n), dim3(256), 0, c.s, a);
+    VAE_LAUNCH_CHECK("sq_rank_rows_k");
+    if (g_allgather(g_allgather_user, d.gath + (backward ? y0.bg_off : y0.fg_off), stride, (vae_stream_t)c.s) != 0)
+        VAE_FAIL(VAE_EINVAL, "seq1d: the all-gather hook failed");
+    return VAE_OK;
+}
+static int sq_exchange_level(const Ctx& c, const SqDesc& d, int i, bool backward, SqTimer* tm) {
+    const SqLayer* ys[SQ_MAXENC];
+    for (int e = 0; e < d.nenc; ++e) ys[e] = &d.enc[e][i];
+    return sq_exchange(c, d, ys, d.nenc, backward, tm, "xe");
+}
+static int sq_exchange_dec(const Ctx& c, const SqDesc& d, int j, bool backward, SqTimer* tm) {
+    const SqLayer* ys[1] = {&d.dec[j]};
+    return sq_exchange(c, d, ys, 1, backward, tm, "xd");
+}
 
 static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int training, SqTimer* tm = nullptr) {
     int rc = sq_bind(c, ops, p, training, false);
@@ -369,6 +440,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
         if (d.nenc == 1) hipLaunchKernelGGL(sq_fe_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fe(d, i, d.SB) * sizeof(float), c.s, d, i);
         else hipLaunchKernelGGL(sq_fe_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fe(d, i, d.SB) * sizeof(float), c.s, d, i);
         VAE_LAUNCH_CHECK("sq_fe_k");
+        if (training && (rc = sq_exchange_level(c, d, i, false, tm)) != VAE_OK) return rc;
     }
     {
         double fl = Bd * (4.0 * d.lat_total + d.dec[0].cin + (double)d.dec[0].cout * d.dec[0].lout) +
@@ -379,6 +451,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
     if (d.nenc == 1) hipLaunchKernelGGL(sq_fh_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     else hipLaunchKernelGGL(sq_fh_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fh(d, d.SB) * sizeof(float), c.s, d);
     VAE_LAUNCH_CHECK("sq_fh_k");
+    if (training && d.dec[0].has_bn && (rc = sq_exchange_dec(c, d, 0, false, tm)) != VAE_OK) return rc;
     for (int j = 1; j < d.ND && !d.prune; ++j) {
         const SqLayer& y = d.dec[j];
         double fl = Bd * ((double)y.cin * y.lin + (double)y.cout * y.lout) + sq_layer_w(y);
@@ -387,6 +460,7 @@ static int sq_forward(const Ctx& c, const vae_op* ops, SqProgram* p, int trainin
         sq_mark(tm, c.s, tag, fl);
         hipLaunchKernelGGL(sq_fd_k, dim3(d.grid), dim3(SQ_THREADS), sq_lds_fd(d, j, d.SB) * sizeof(float), c.s, d, j);
         VAE_LAUNCH_CHECK("sq_fd_k");
+        if (training && y.has_bn && (rc = sq_exchange_dec(c, d, j, false, tm)) != VAE_OK) return rc;
     }
     if (p->elbo >= 0 && !(ops[p->elbo].flags & VAE_F_LOSS_IN_BWD)) {  // fixed-order sum of the workgroups' {recon, kld} partials -> out[0..3]
         const vae_op& eo = ops[p->elbo];
@@ -420,6 +494,7 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* t
         sq_mark(tm, c.s, tag, Bd * (gy + 2.0 * y.cin * y.lin) + 2.0 * sq_layer_w(y));
         hipLaunchKernelGGL(sq_bd_k, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bd(d, j, d.SB) * sizeof(float), c.s, d, j);
         VAE_LAUNCH_CHECK("sq_bd_k");
+        if ((rc = sq_exchange_dec(c, d, j - 1, true, tm)) != VAE_OK) return rc;   // the sums of dec[j-1]'s BatchNorm
     }
     {
         double fl = Bd * (2.0 * d.dec[0].cout * d.dec[0].lout + d.dec[0].cin + 4.0 * d.lat_total) +
@@ -430,6 +505,7 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* t
     if (d.nenc == 1) hipLaunchKernelGGL(sq_bh_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bh(d, d.SB) * sizeof(float), c.s, d);
     else hipLaunchKernelGGL(sq_bh_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_bh(d, d.SB) * sizeof(float), c.s, d);
     VAE_LAUNCH_CHECK("sq_bh_k");
+    if ((rc = sq_exchange_level(c, d, d.NE - 1, true, tm)) != VAE_OK) return rc;
     for (int i = d.NE - 1; i >= 0; --i) {
         double fl = 0;
         for (int e = 0; e < d.nenc; ++e) {
@@ -441,6 +517,7 @@ static int sq_backward(const Ctx& c, const vae_op* ops, SqProgram* p, SqTimer* t
         if (d.nenc == 1) hipLaunchKernelGGL(sq_be_k<1>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_be(d, i, d.SB) * sizeof(float), c.s, d, i);
         else hipLaunchKernelGGL(sq_be_k<2>, dim3(d.grid), dim3(SQ_THREADS), sq_lds_be(d, i, d.SB) * sizeof(float), c.s, d, i);
         VAE_LAUNCH_CHECK("sq_be_k");
+        if (i > 0 && (rc = sq_exchange_level(c, d, i - 1, true, tm)) != VAE_OK) return rc;
     }
     sq_mark(tm, c.s, "reduce", (double)d.nflat * (d.grid + 1));
     hipLaunchKernelGGL(sq_reduce_k, dim3((unsigned)ceil_div64(d.nflat, SQR_COLS)), dim3(256), 0, c.s, d.part, grad, d.nflat, d.grid);

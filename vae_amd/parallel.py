@@ -165,15 +165,18 @@ class DataParallelTrainStep(FusedTrainStep):
     bucket follows.  `loss` is this rank's shard loss; `global_loss()` sums it over the ranks."""
 
     def __init__(self, model, optimizer, B, device, bce=None, group=None, native=None, use_graph=False,
-                 single_comm=None):
+                 single_comm=None, allow_seq1d=True):
         """native: the exchanges are enqueued by the library itself over RCCL (vae_dp_*: no Python between the kernels
         of a step; default on the nccl backend); otherwise through torch.distributed from the SyncBN callback (gloo:
         CPU tests, ranks sharing one GPU).  use_graph (native only): the whole step, collectives included, is captured
         into one hipGraph and replayed.  single_comm (native only; None: environment variable VAE_DP_SINGLE_COMM):
         one RCCL communicator and ONE stream for the SyncBN gathers and the gradient all-reduces -- no two collectives
         in flight together, no overlap; the fallback should the two-communicator overlap stall on a system."""
-        # (the whole-model 1-D path has no synchronised BatchNorm yet: data parallel keeps the per-layer program)
-        super().__init__(model, optimizer, B, device, bce=bce, use_graph=False, allow_seq1d=False)
+        # The 1-D families keep their whole-model path (one launch per BatchNorm-delimited phase): between two phases
+        # every rank folds its workgroups' statistics rows into one row, the rows are all-gathered through the same
+        # hook, and the next phase's prologue merges `world` rows (seq1d_host.h: sq_exchange).  allow_seq1d=False:
+        # the per-layer program.
+        super().__init__(model, optimizer, B, device, bce=bce, use_graph=False, allow_seq1d=allow_seq1d)
         self.coll = Collective(group)
         self.native = (self.coll.backend == "nccl" and self.device.type == "cuda") if native is None else bool(native)
         self.hook_calls = 0  # SyncBN callbacks into Python (0 on the native path)
