@@ -21,6 +21,7 @@
 #include "lin.h"
 #include "wide.h"
 #include "thin.h"
+#include "scat.h"
 #include "fc.h"
 #include <stdlib.h>
 
@@ -930,6 +931,27 @@ static bool mid_conv_geom_ok(const IgGeom& q) {
     return !g_bf16 && !q.transposed && q.so_h == 1 && q.so_w == 1 && q.N <= 16 && q.Cin * q.KH * q.KW <= 4 * MIDC_KS &&
            q.OH * q.OW <= 64 && q.Cin * q.H * q.W <= 256 * MIDC_NE;
 }
+// transposed 3x3 stride-2 gathers that run as GEMM + col2im on scat_convT_k (scat.h); returns the samples per round
+// (0: not this kernel) and the instance: 1 = <= 8 produced channels from <= 16, 2 = <= 16 from <= 32
+static int scat_geom_sbr(const IgGeom& q, int* inst) {
+    if (g_bf16 || !q.transposed || q.so_h != 2 || q.so_w != 2 || q.KH != 3 || q.KW != 3) return 0;
+    const int cls = (q.N <= 8 && q.Cin <= 16) ? 1 : (q.N <= 16 && q.Cin <= 32) ? 2 : 0;
+    if (cls == 0) return 0;
+    const int HW = q.H * q.W, OHW = q.OH * q.OW, CHW = q.Cin * HW;
+    if ((CHW & 3) || HW > 64 || OHW > TH_THREADS) return 0;
+    int sbr = 64 / HW;
+    if (TH_THREADS / OHW < sbr) sbr = TH_THREADS / OHW;
+    const int nj = cls == 1 ? 1 : 2;
+    if (nj * 4 * TH_THREADS / CHW < sbr) sbr = nj * 4 * TH_THREADS / CHW;
+    if (sbr < 1) return 0;
+    while (sbr & (sbr - 1)) sbr &= sbr - 1;  // a power of two: batches usually are, and the rounds then deal out evenly
+    *inst = cls;
+    return sbr;
+}
+static bool scat_enabled() {
+    static const int on = [] { const char* e = getenv("VAE_AMD_SCAT"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
+    return on != 0;
+}
 extern "C" int vae_conv_fused_ok(const vae_op* op, int B);
 static int gather_direct_nd(const IgGeom& g, const IgClass* cls, int ncls);
 extern "C" int vae_conv_forward_variant(const vae_op* op, int B) {
@@ -941,6 +963,8 @@ extern "C" int vae_conv_forward_variant(const vae_op* op, int B) {
     {
         static const int mid_on = [] { const char* e = getenv("VAE_AMD_MID"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
         if (mid_on && mid_conv_geom_ok(f)) return 400;  // mid_conv_k
+        int inst = 0;
+        if (mid_on && scat_enabled() && scat_geom_sbr(f, &inst) > 0) return 500;  // scat_convT_k
     }
     IgClass cls[4];
     int wsum, tsum;
@@ -1046,6 +1070,48 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
             VAE_TBYTES(4.0 * ((double)c.B * ((double)q.Cin * q.H * q.W * (gradin ? 2 : 1) +
                                              (double)q.N * q.OH * q.OW * ((gradin && epbn) ? 2 : 1)) + (double)q.Cin * q.KH * q.KW * q.N));
             VAE_LAUNCH_CHECK("mid_conv_k");
+            if (a.slab != nullptr) c.last_blocks = grid;
+            return VAE_OK;
+        }
+    }
+    {   // transposed 3x3 stride-2 gathers of mid-size layers: GEMM over the input pixels + col2im (scat.h)
+        static const int mid_on = [] { const char* e = getenv("VAE_AMD_MID"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
+        const IgGeom& q = a.g;
+        const bool gradin = a.in.mode >= TR_GRAD_BN;
+        const int actv = gradin ? a.in.act : a.act;
+        int inst = 0;
+        const int sbr = (mid_on && scat_enabled()) ? scat_geom_sbr(q, &inst) : 0;
+        if (sbr > 0 && (!gradin || (a.act == VAE_ACT_NONE && a.bias == nullptr)) && (a.ep_mode == EP_PLAIN || gradin) &&
+            (a.fin.C == 0 || (!gradin && a.fin.C == q.Cin))) {
+            const int rounds = (c.B + sbr - 1) / sbr;
+            int grid = mid_grid(rounds);
+            if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
+            a.SB = sbr;
+            const int co = inst == 1 ? 8 : 16, ks = inst == 1 ? 4 : 8, mp = 16 * ((9 * co + 15) / 16);
+            const size_t sbytes = (size_t)(2 * 4 * ks * SC_BP + (SC_ZROW + 1) * mp + 4 * q.Cin + 4 + 5 * co + 4 + 10 * co) * sizeof(float);
+            const int ep = !gradin ? 0 : (a.ep_mode == EP_BNGRAD ? 2 : 1);
+#define SCAT_LAUNCH(CO, KS, NJ, IN, EP, AC) hipLaunchKernelGGL((scat_convT_k<CO, KS, NJ, IN, EP, AC>), dim3(grid), dim3(TH_THREADS), sbytes, c.s, a)
+#define SCAT_ACT(CO, KS, NJ, IN, EP)                                                     \
+    do {                                                                                 \
+        if (actv == VAE_ACT_SIGMOID) SCAT_LAUNCH(CO, KS, NJ, IN, EP, VAE_ACT_SIGMOID);   \
+        else if (actv == VAE_ACT_LEAKY) SCAT_LAUNCH(CO, KS, NJ, IN, EP, VAE_ACT_LEAKY);  \
+        else SCAT_LAUNCH(CO, KS, NJ, IN, EP, VAE_ACT_NONE);                              \
+    } while (0)
+#define SCAT_EP(CO, KS, NJ)                        \
+    do {                                           \
+        if (ep == 0) SCAT_ACT(CO, KS, NJ, 0, 0);   \
+        else if (ep == 1) SCAT_ACT(CO, KS, NJ, 1, 1); \
+        else SCAT_ACT(CO, KS, NJ, 1, 2);           \
+    } while (0)
+            if (inst == 1) SCAT_EP(8, 4, 1);
+            else SCAT_EP(16, 8, 2);
+#undef SCAT_EP
+#undef SCAT_ACT
+#undef SCAT_LAUNCH
+            VAE_TNAME("scat_convT_k<%d, %d, %d, %d, %d, %d>", co, ks, inst == 1 ? 1 : 2, gradin ? 1 : 0, ep, actv);
+            VAE_TBYTES(4.0 * ((double)c.B * ((double)q.Cin * q.H * q.W * (gradin ? 2 : 1) +
+                                             (double)q.N * q.OH * q.OW * (ep == 2 ? 2 : 1)) + (double)q.Cin * q.KH * q.KW * q.N));
+            VAE_LAUNCH_CHECK("scat_convT_k");
             if (a.slab != nullptr) c.last_blocks = grid;
             return VAE_OK;
         }
