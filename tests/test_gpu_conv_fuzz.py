@@ -28,6 +28,11 @@ GEOMS = [
     (7, 5, 4, 9, 4, 3, 2, 1, True, 0, 12),
     (3, 8, 8, 5, 3, 3, 1, 1, True, 0, 17),          # transposed, stride 1
     (2, 10, 10, 2, 5, 5, 2, 2, True, 1, 9),
+    # GEMM + col2im kernel of scat.h (3x3 stride 2 transposed; the input gradient of a 3x3 stride-2 conv): odd channel
+    # counts below the tile sizes, two samples per round, a ragged last round
+    (12, 5, 6, 7, 3, 3, 2, 1, True, 1, 27),
+    (20, 4, 4, 11, 3, 3, 2, 0, True, 0, 31),
+    (6, 10, 10, 12, 3, 3, 2, 1, False, 0, 25),
     # wide layers: the K-loop MFMA kernels of wide.h (forward, input gradient and weight gradient)
     (32, 14, 14, 64, 3, 3, 2, 1, False, 0, 40),
     (64, 7, 7, 128, 3, 3, 2, 0, False, 0, 21),

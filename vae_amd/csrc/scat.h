@@ -22,10 +22,13 @@
 
 #define SC_BP 80    // row stride of the B image: 64 pixel columns + 16, so that the four k rows of an MFMA step hit different banks
 #define SC_ZROW 64  // the all-zero row of the product tile that absent taps read
+// row stride of the product tile [pixel][(tap, co)]: the row tiles + 4 floats, = 20 (mod 64): the sixteen pixel lanes of
+// a 16-byte store land in sixteen different bank quads (with a multiple of 16 floats they shared four)
+#define SC_MP(CO) (16 * ((9 * (CO) + 15) / 16) + 4)
 
 template <int CO, int KS, int NJ, int IN, int EP, int ACT>
 __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
-    constexpr int MT = (9 * CO + 15) / 16, MP = 16 * MT, KR = 4 * KS, CV = CO / 4;
+    constexpr int MT = (9 * CO + 15) / 16, MP = SC_MP(CO), KR = 4 * KS, CV = CO / 4;
     // who owns which product tiles: few row tiles (MT <= 5): wave w takes the pixel tile w and every row tile; many:
     // wave w takes the row tiles w, w + 4, ... of every pixel tile (a third of the weight registers)
     constexpr bool MSPLIT = MT > 5;
@@ -43,6 +46,8 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
     const int nrounds = (a.B + SBR - 1) / SBR;
     const int vps = CHW >> 2, nvec = SBR * vps;  // float4 per sample / per round (the host checks 4 | CHW)
 
+    IG_TDECL;
+    IG_T();
     BnFinRegs finr;
     if (IN == 0) bnfin_issue<false>(a.fin, finr);
 
@@ -69,9 +74,13 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
     };
     load(blockIdx.x, vA, yA);
     load(blockIdx.x + G, vB, yB);
+    IG_T();
 
     // ---- once per workgroup
-    for (int e = tid; e < 2 * KR * SC_BP + (SC_ZROW + 1) * MP; e += TH_THREADS) smem[e] = 0.f;  // k rows >= Cin, pixel columns past the round, the zero row
+    // What has to be zero: the k rows >= Cin of both B images (their weights are zero, but 0 * garbage may be NaN) and
+    // the zero row of the product tile.  Pixel columns past the round only feed product columns that nobody reads.
+    for (int e = g.Cin * SC_BP + tid; e < KR * SC_BP; e += TH_THREADS) bm[0][e] = bm[1][e] = 0.f;
+    for (int e = tid; e < MP; e += TH_THREADS) yf[SC_ZROW * MP + e] = 0.f;
     if (IN) {
         for (int e = tid; e < 4 * g.Cin; e += TH_THREADS) {
             const int q = e / g.Cin, c = e - q * g.Cin;
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         if (tid == 0) cep[4 * N] = a.ep_relu ? 0.f : -__builtin_inff();
     }
     if (EP == 0 && tid < CO) cep[4 * CO + 4 + tid] = (a.bias != nullptr && tid < N) ? a.bias[tid] : 0.f;
+    IG_T();
     int dst[NJ][4], chn[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) wreg[i][s] = (tap < 9 && co < N && 4 * s + lk < g.Cin) ? wreg[i][s] : 0.f;
     }
+    IG_T();
     // col2im: this thread's (sample of the round, output pixel) and the <= 4 products that land on it
     const bool q_ok = tid < SBR * OHW;
     const int q_c = q_ok ? tid : 0;
@@ -147,14 +158,13 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
     float s1[CO], s2[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) s1[c] = s2[c] = 0.f;
+    IG_T();
     __syncthreads();
     if (IN == 0 && a.fin.C > 0) {
         // every workgroup finalises the producer BatchNorm from its accumulators (requested at the top); the scratch
-        // lies over the B images, which are zeroed again behind it
-        static_assert(2 * KR * SC_BP >= BNFIN_SCR_FLOATS, "the finalize prologue's scratch lies over the B images");
-        bnfin_forward<TH_THREADS>(a.fin, finr, cin, smem);
-        for (int e = tid; e < BNFIN_SCR_FLOATS; e += TH_THREADS) smem[e] = 0.f;
-        __syncthreads();
+        // lies over the product rows, which are written before they are read
+        static_assert(SC_ZROW * MP >= BNFIN_SCR_FLOATS, "the finalize prologue's scratch lies over the product tile");
+        bnfin_forward<TH_THREADS>(a.fin, finr, cin, yf);  // (ends with a barrier)
     }
     const float thr_in = IN ? 0.f : cin[4 * g.Cin];
     const float thr_ep = EP == 2 ? cep[4 * N] : 0.f;
@@ -257,16 +267,22 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         }
     };
 
+    IG_T();
     store(bm[0], vA, yA);
     load(blockIdx.x + 2 * G, vA, yA);
     for (int r = blockIdx.x; r < nrounds; r += 2 * G) {
         lds_barrier();  // image 0 is complete, the product tile is free
+        IG_T();
         ep_load(r);
         products(bm[0]);
+        IG_T();
         store(bm[1], vB, yB);
         load(r + 3 * G, vB, yB);
+        IG_T();
         lds_barrier();  // the products are complete
+        IG_T();
         scatter(r);
+        IG_T();
         lds_barrier();
         ep_load(r + G);
         products(bm[1]);
@@ -275,6 +291,8 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         lds_barrier();
         scatter(r + G);
     }
+    IG_T();
+    IG_TPRINT("scat: loads zero+coef dst+weights entries [sync/bnfin] | store0 | [barrier] products store+load [barrier] scatter (second round) ... end");
 
     if (a.slab == nullptr || EP == 1) return;  // (uniform)
     // ---- per-channel sums over the workgroup -> its slab row and the BatchNorm's accumulators

@@ -1084,10 +1084,12 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
         if (sbr > 0 && (!gradin || (a.act == VAE_ACT_NONE && a.bias == nullptr)) && (a.ep_mode == EP_PLAIN || gradin) &&
             (a.fin.C == 0 || (!gradin && a.fin.C == q.Cin))) {
             const int rounds = (c.B + sbr - 1) / sbr;
-            int grid = mid_grid(rounds);
+            static const int cap = [] { const char* e = getenv("VAE_SCAT_GRID"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 512; }();
+            int grid = rounds < cap ? rounds : cap;
+            if (grid > MID_MAX_GRID) grid = MID_MAX_GRID;
             if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
             a.SB = sbr;
-            const int co = inst == 1 ? 8 : 16, ks = inst == 1 ? 4 : 8, mp = 16 * ((9 * co + 15) / 16);
+            const int co = inst == 1 ? 8 : 16, ks = inst == 1 ? 4 : 8, mp = SC_MP(co);
             const size_t sbytes = (size_t)(2 * 4 * ks * SC_BP + (SC_ZROW + 1) * mp + 4 * q.Cin + 4 + 5 * co + 4 + 10 * co) * sizeof(float);
             const int ep = !gradin ? 0 : (a.ep_mode == EP_BNGRAD ? 2 : 1);
 #define SCAT_LAUNCH(CO, KS, NJ, IN, EP, AC) hipLaunchKernelGGL((scat_convT_k<CO, KS, NJ, IN, EP, AC>), dim3(grid), dim3(TH_THREADS), sbytes, c.s, a)
