@@ -18,6 +18,8 @@
 //           channel.  One slab row per workgroup, and the BatchNorm's fixed-point accumulators (igemm.h).
 // Uses IgArgs (igemm.h) like mid_conv_k: geometry (of the transposed gather), tensors, epilogue; SB = samples per round.
 #pragma once
+#include <type_traits>
+
 #include "thin.h"
 
 #define SC_BP 80    // row stride of the B image: 64 pixel columns + 16, so that the four k rows of an MFMA step hit different banks
@@ -27,20 +29,25 @@
 #define SC_MP(CO) (16 * ((9 * (CO) + 15) / 16) + 4)
 
 template <int CO, int KS, int NJ, int IN, int EP, int ACT>
-__global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
+__global__ __launch_bounds__(TH_THREADS, 2) void scat_convT_k(IgArgs a) {  // (two workgroups per CU: <= 256 registers, accumulation registers included)
     constexpr int MT = (9 * CO + 15) / 16, MP = SC_MP(CO), KR = 4 * KS, CV = CO / 4;
     // who owns which product tiles: few row tiles (MT <= 5): wave w takes the pixel tile w and every row tile; many:
     // wave w takes the row tiles w, w + 4, ... of every pixel tile (a third of the weight registers)
     constexpr bool MSPLIT = MT > 5;
     constexpr int MTW = MSPLIT ? (MT + 3) / 4 : MT;
+    // PIPE: two product tiles; between two barriers a wave takes the products of round r + 1 (matrix pipe) and the
+    // col2im of round r (LDS reads, vector ALU, stores): one barrier per round instead of two, and the two kinds of
+    // work overlap.  (Not for the 16-channel instances: their tiles are 38 KB each and a workgroup has 2 rounds.)
+    constexpr bool PIPE = !MSPLIT;
+    constexpr int YF = (SC_ZROW + 1) * MP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const IgGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int HW = g.H * g.W, CHW = g.Cin * HW, OHW = g.OH * g.OW, SBR = a.SB, N = g.N;
     float* bm[2] = {smem, smem + KR * SC_BP};   // B image [k = ci][pixel of the round], double-buffered
-    float* yf = smem + 2 * KR * SC_BP;          // products [pixel][(tap, co)] + the zero row
-    float* cin = yf + (SC_ZROW + 1) * MP;       // input coefficients [4 * Cin + 4]
-    float* cep = cin + 4 * g.Cin + 4;           // EP 2: producer BatchNorm [4 * N + 4]; EP 0: bias at [4 * CO + 4, 5 * CO + 4)
+    float* yf = smem + 2 * KR * SC_BP;          // products [pixel][(tap, co)] + the zero row (PIPE: two of them)
+    float* cin = yf + (PIPE ? 2 : 1) * YF;      // input coefficients [4 * Cin + 4]
+    float* cep = cin + 4 * g.Cin + 4;           // EP 2: producer BatchNorm [CO][4] + threshold; EP 0: bias at [4 * CO + 4, 5 * CO + 4)
     float* red = cep + 5 * CO + 4;              // [4][2 * CO] + [2 * CO]
     const int G = gridDim.x, last = a.B - 1;
     const int nrounds = (a.B + SBR - 1) / SBR;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         rem[j] = (e4c - s_l[j] * vps) * 4;
     }
     f32x4 vA[NJ], vB[NJ], yA[IN ? NJ : 1], yB[IN ? NJ : 1];
-    auto load = [&](int r, f32x4 (&v)[NJ], f32x4 (&y)[IN ? NJ : 1]) {
+    auto load = [&](int r, f32x4 (&v)[NJ], f32x4 (&y)[IN ? NJ : 1]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int s = min(r * SBR + s_l[j], last);
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
     // What has to be zero: the k rows >= Cin of both B images (their weights are zero, but 0 * garbage may be NaN) and
     // the zero row of the product tile.  Pixel columns past the round only feed product columns that nobody reads.
     for (int e = g.Cin * SC_BP + tid; e < KR * SC_BP; e += TH_THREADS) bm[0][e] = bm[1][e] = 0.f;
-    for (int e = tid; e < MP; e += TH_THREADS) yf[SC_ZROW * MP + e] = 0.f;
+    for (int e = tid; e < MP; e += TH_THREADS) yf[SC_ZROW * MP + e] = yf[(PIPE ? YF : 0) + SC_ZROW * MP + e] = 0.f;
     if (IN) {
         for (int e = tid; e < 4 * g.Cin; e += TH_THREADS) {
             const int q = e / g.Cin, c = e - q * g.Cin;
@@ -96,9 +103,9 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         }
     }
     if (!IN && tid == 0) cin[4 * g.Cin] = (a.in.mode == TR_BN && a.in.relu) ? 0.f : -__builtin_inff();
-    if (EP == 2) {
-        for (int e = tid; e < 4 * N; e += TH_THREADS) cep[e] = a.ep_coef[e];
-        if (tid == 0) cep[4 * N] = a.ep_relu ? 0.f : -__builtin_inff();
+    if (EP == 2) {  // one 16-byte row {mean, rstd, scale, beta} per produced channel (rows past N repeat the last one)
+        for (int e = tid; e < 4 * CO; e += TH_THREADS) cep[e] = a.ep_coef[(e & 3) * N + min(e >> 2, N - 1)];
+        if (tid == 0) cep[4 * CO] = a.ep_relu ? 0.f : -__builtin_inff();
     }
     if (EP == 0 && tid < CO) cep[4 * CO + 4 + tid] = (a.bias != nullptr && tid < N) ? a.bias[tid] : 0.f;
     IG_T();
@@ -166,10 +173,15 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         static_assert(SC_ZROW * MP >= BNFIN_SCR_FLOATS, "the finalize prologue's scratch lies over the product tile");
         bnfin_forward<TH_THREADS>(a.fin, finr, cin, yf);  // (ends with a barrier)
     }
+    float bias_r[(EP == 0 && CO <= 8) ? CO : 1];  // EP 0, 8 channels: the bias of every produced channel (zero past N) in registers
+    if (EP == 0 && CO <= 8) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) bias_r[c] = cep[4 * CO + 4 + c];
+    }
     const float thr_in = IN ? 0.f : cin[4 * g.Cin];
-    const float thr_ep = EP == 2 ? cep[4 * N] : 0.f;
+    const float thr_ep = EP == 2 ? cep[4 * CO] : 0.f;
 
-    auto store = [&](float* t, const f32x4 (&v)[NJ], const f32x4 (&y)[IN ? NJ : 1]) {
+    auto store = [&](float* t, const f32x4 (&v)[NJ], const f32x4 (&y)[IN ? NJ : 1]) __attribute__((always_inline)) {
         float o[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -190,14 +202,14 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
             }
     };
     const int ntl = (SBR * HW + 15) >> 4;  // pixel tiles that hold pixels of the round
-    auto products = [&](const float* t) {
+    auto products = [&](const float* t, float* yo) __attribute__((always_inline)) {
         if (MSPLIT) {
             for (int nt = 0; nt < ntl; ++nt) {
                 const float* p = t + lk * SC_BP + 16 * nt + li;
                 float b[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) b[s] = p[4 * s * SC_BP];
-                float* o = yf + (16 * nt + li) * MP + 4 * lk;
+                float* o = yo + (16 * nt + li) * MP + 4 * lk;
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) {
                     if (wid + 4 * i >= MT) continue;  // (wave-uniform)
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
             float b[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) b[s] = p[4 * s * SC_BP];
-            float* o = yf + (16 * wid + li) * MP + 4 * lk;
+            float* o = yo + (16 * wid + li) * MP + 4 * lk;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -224,14 +236,21 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         }
     };
     float ev[EP == 2 ? CO : 1];
-    auto ep_load = [&](int r) {  // EP 2: the producer's outputs at this thread's output pixel, requested before the products
+    auto ep_load = [&](int r) __attribute__((always_inline)) {  // EP 2: the producer's outputs at this thread's output pixel, requested before the products
         if (EP != 2) return;
         const int s = min(r * SBR + q_s, last);
-        const float* py = a.ep_y + (int64_t)s * N * OHW + q_p;
+        // (opaque pixel index: otherwise every channel's 64-bit address is hoisted out of the round loop, once per
+        // inlined copy, and the 16-channel instances run out of registers)
+        int qp = q_p;
+        asm volatile("" : "+v"(qp));
+        const float* py = a.ep_y + (int64_t)s * N * OHW + qp;
 #pragma unroll
         for (int c = 0; c < CO; ++c) ev[c] = py[min(c, N - 1) * OHW];
     };
-    auto scatter = [&](int r) {
+    const bool nfull = CO <= 8 && N == CO;  // (uniform) every produced channel exists: no masks on the stores (8-channel instances: the 16-channel ones have no registers for a second copy of the epilogue)
+    // (always_inline: called twice, the compiler left it out of line and its captured arrays went to scratch memory)
+    auto scatter_f = [&](int r, const float* yi, auto full) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;
         const int s = r * SBR + q_s;
         if (!q_ok || s > last) return;
         f32x4 sum[CV];
@@ -239,60 +258,99 @@ __global__ __launch_bounds__(TH_THREADS) void scat_convT_k(IgArgs a) {
         for (int h = 0; h < CV; ++h) sum[h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4* y = reinterpret_cast<const f32x4*>(yf + ent[e]);
+            const f32x4* y = reinterpret_cast<const f32x4*>(yi + ent[e]);
 #pragma unroll
             for (int h = 0; h < CV; ++h) sum[h] += y[h];
         }
-        float* o = a.out + (int64_t)s * N * OHW + q_p;
+        int qp = q_p;
+        asm volatile("" : "+v"(qp));  // (see ep_load)
+        float* o = a.out + (int64_t)s * N * OHW + qp;
+        // (no per-channel branches: a `continue` on c >= N put a branch and an LDS wait in front of every channel.
+        // Channels >= N compute on zero products and clamped coefficients; only their stores are masked.)
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            if (c >= N) continue;
             const float acc = sum[c >> 2][c & 3];
+            float v;
             if (EP == 2) {
-                const float xc = ev[c] - cep[c];
-                const float d = fmaf(xc, cep[2 * N + c], cep[3 * N + c]) > thr_ep ? acc : 0.f;
-                s1[c] += d;
-                s2[c] = fmaf(d, xc * cep[N + c], s2[c]);
-                o[c * OHW] = d;
+                const f32x4 q = *reinterpret_cast<const f32x4*>(cep + 4 * c);
+                const float xc = ev[c] - q[0];
+                v = fmaf(xc, q[2], q[3]) > thr_ep ? acc : 0.f;
+                s1[c] += v;
+                s2[c] = fmaf(v, xc * q[1], s2[c]);
             } else if (EP == 1) {
-                o[c * OHW] = acc;
+                v = acc;
             } else {
-                const float bs = cep[4 * CO + 4 + c];
-                const float v = th_act<ACT>(acc + bs, a.slope);
-                o[c * OHW] = v;
+                const float bs = CO <= 8 ? bias_r[c] : cep[4 * CO + 4 + c];
+                v = th_act<ACT>(acc + bs, a.slope);
                 const float d = v - bs;  // statistics pivot: the channel's bias
                 s1[c] += d;
                 s2[c] = fmaf(d, d, s2[c]);
             }
+            if (FULL || c < N) o[c * OHW] = v;
+            // (16 channels: without a fence every four channels the scheduler hoists all 64 coefficient reads and the
+            // kernel needs > 256 registers: one workgroup per CU, 22.7 -> 30.8 us)
+            if (CO > 8 && (EP == 2 || (c & 3) == 3)) asm volatile("" ::: "memory");
         }
+    };
+    auto scatter = [&](int r, const float* yi) __attribute__((always_inline)) {
+        if (nfull) scatter_f(r, yi, std::true_type{});
+        else scatter_f(r, yi, std::false_type{});
     };
 
     IG_T();
     store(bm[0], vA, yA);
     load(blockIdx.x + 2 * G, vA, yA);
-    for (int r = blockIdx.x; r < nrounds; r += 2 * G) {
-        lds_barrier();  // image 0 is complete, the product tile is free
-        IG_T();
-        ep_load(r);
-        products(bm[0]);
-        IG_T();
+    if (PIPE) {
+        lds_barrier();
+        products(bm[0], yf);
         store(bm[1], vB, yB);
-        load(r + 3 * G, vB, yB);
-        IG_T();
-        lds_barrier();  // the products are complete
-        IG_T();
-        scatter(r);
-        IG_T();
+        load(blockIdx.x + 3 * G, vB, yB);
         lds_barrier();
-        ep_load(r + G);
-        products(bm[1]);
-        store(bm[0], vA, yA);
-        load(r + 4 * G, vA, yA);
-        lds_barrier();
-        scatter(r + G);
+        for (int r = blockIdx.x; r < nrounds; r += 2 * G) {
+            // image 1 and product tile 0 are complete; image 0 and product tile 1 are free
+            IG_T();
+            ep_load(r);
+            products(bm[1], yf + YF);
+            IG_T();
+            scatter(r, yf);
+            IG_T();
+            store(bm[0], vA, yA);
+            load(r + 4 * G, vA, yA);
+            IG_T();
+            lds_barrier();
+            IG_T();
+            ep_load(r + G);
+            products(bm[0], yf);
+            scatter(r + G, yf + YF);
+            store(bm[1], vB, yB);
+            load(r + 5 * G, vB, yB);
+            lds_barrier();
+        }
+    } else {
+        for (int r = blockIdx.x; r < nrounds; r += 2 * G) {
+            lds_barrier();  // image 0 is complete, the product tile is free
+            IG_T();
+            ep_load(r);
+            products(bm[0], yf);
+            IG_T();
+            store(bm[1], vB, yB);
+            load(r + 3 * G, vB, yB);
+            IG_T();
+            lds_barrier();  // the products are complete
+            IG_T();
+            scatter(r, yf);
+            IG_T();
+            lds_barrier();
+            ep_load(r + G);
+            products(bm[1], yf);
+            store(bm[0], vA, yA);
+            load(r + 4 * G, vA, yA);
+            lds_barrier();
+            scatter(r + G, yf);
+        }
     }
     IG_T();
-    IG_TPRINT("scat: loads zero+coef dst+weights entries [sync/bnfin] | store0 | [barrier] products store+load [barrier] scatter (second round) ... end");
+    IG_TPRINT("scat: loads zero+coef dst+weights entries [sync/bnfin] | pipe: (prologue) products scatter store+load [barrier] (second round) ... | else: store0 [barrier] products store+load [barrier] scatter (second round) ...");
 
     if (a.slab == nullptr || EP == 1) return;  // (uniform)
     // ---- per-channel sums over the workgroup -> its slab row and the BatchNorm's accumulators

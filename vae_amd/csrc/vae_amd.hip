@@ -1090,7 +1090,7 @@ static int launch_igemm_gather(const Ctx& c, IgArgs& a, const char* what) {
             if (grid > a.nchunks) grid = a.nchunks;  // (the callers sized the slab for nchunks rows)
             a.SB = sbr;
             const int co = inst == 1 ? 8 : 16, ks = inst == 1 ? 4 : 8, mp = SC_MP(co);
-            const size_t sbytes = (size_t)(2 * 4 * ks * SC_BP + (SC_ZROW + 1) * mp + 4 * q.Cin + 4 + 5 * co + 4 + 10 * co) * sizeof(float);
+            const size_t sbytes = (size_t)(2 * 4 * ks * SC_BP + (inst == 1 ? 2 : 1) * (SC_ZROW + 1) * mp + 4 * q.Cin + 4 + 5 * co + 4 + 10 * co) * sizeof(float);  // (two product tiles for the pipelined 8-channel instances)
             const int ep = !gradin ? 0 : (a.ep_mode == EP_BNGRAD ? 2 : 1);
 #define SCAT_LAUNCH(CO, KS, NJ, IN, EP, AC) hipLaunchKernelGGL((scat_convT_k<CO, KS, NJ, IN, EP, AC>), dim3(grid), dim3(TH_THREADS), sbytes, c.s, a)
 #define SCAT_ACT(CO, KS, NJ, IN, EP)                                                     \
