@@ -210,7 +210,8 @@ def test_bench_workload_at_full_size():
 
 def test_widened_model_vs_oracle():
     """BASELINE configs[4]: the MNIST VAE with 4x conv channels (32/64/128) and latent 256.  Layers beyond the
-    fused kernels' budgets fall back to the direct HIP kernels; results must not depend on which path ran."""
+    LDS-resident kernels' budgets run on the K-loop MFMA kernels of wide.h with a materialised BatchNorm; results
+    must not depend on which path ran."""
     import vae_amd
     from oracle import vae_oracle as O
     B = 96

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void convT_gather_k(const float* __restrict__ 
 // Weight gradient.  S: [B][A][SH][SW] (small grid), G: [B][C][GH][GW] (big grid).
 // grid.x = chunks of the (b,oh,ow) reduction, grid.y = a-tile * C + c, grid.z = tap group.
 // Each lane accumulates AT x TG partial sums over its pixels; wave shuffle + LDS reduce;
-// one atomicAdd per (block, element) into dw (dw is zeroed once per step by the executor).
+// one atomicAdd per (block, element) into dw (dw is zeroed once per step by the executor).  Float atomics: the
+// gradients of a layer that falls back to this kernel are NOT bit-reproducible from run to run (none of the benched
+// models has such a layer; DESIGN.md, data layout).
 template <int AT, int TG>
 __global__ __launch_bounds__(256) void conv_wgrad_k(const float* __restrict__ S, const float* __restrict__ G,
                                                     float* __restrict__ dw, int B, int A, int SH, int SW, int C,

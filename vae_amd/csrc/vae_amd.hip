@@ -340,7 +340,8 @@ static int conv_backward(const Ctx& c, const vae_op& op) {
     float* dw = resolve(c, ((int64_t)2 << 56) | ref_off(op.r[4]), nw, "conv.dw", &ok);
     float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), g.Cout, "conv.db", &ok);
     float* part = resolve(c, op.r[6], (int64_t)2 * g.Cout * VAE_MAX_CHUNKS, "conv.partials", &ok);
-    // optional own region for the wide weight-gradient kernel's partial sums (else: float atomics)
+    // own region for the wide weight-gradient kernel's partial sums (without one: float atomics, not bit-reproducible;
+    // program.py always provides it)
     const bool T = op.kind == VAE_OP_CONVT;
     const WideWgPlan wp = T ? wide_wgrad_plan(c.B, g.Cin, g.H, g.W, g.Cout, g.KH, g.KW)
                             : wide_wgrad_plan(c.B, g.Cout, g.OH, g.OW, g.Cin, g.KH, g.KW);
@@ -1770,7 +1771,8 @@ static int linear_backward(const Ctx& c, const vae_op& op, const vae_op* sib = n
     float* db = op.r[5] < 0 ? nullptr : resolve(c, ((int64_t)2 << 56) | ref_off(op.r[5]), N, "linear.db", &ok);
     if (!ok) return VAE_EINVAL;
 
-    // 1) dW[N][K] += (dY*act')^T X and db[N] += colsum(dY*act'): batch-chunked MFMA, atomics into the zeroed grads
+    // 1) dW[N][K] = (dY*act')^T X and db[N] = colsum(dY*act'): batch-chunked MFMA, one partial row per batch slice in the
+    //    layer's own region, summed in a fixed order by wgrad_finalize_k (deferred launch; no float atomics)
     LinWgArgs wa;
     memset(&wa, 0, sizeof(wa));
     wa.dY = dy; wa.Y = y; wa.X = x; wa.dW = dw; wa.db = db;
@@ -2425,8 +2427,9 @@ extern "C" int vae_run_backward_range(const vae_op* ops, int n_ops, float* const
             return sq_backward(c, ops, &sq);
         }
     }
-    // weight gradients accumulate with atomics: start from zero (cleared by the ELBO op's kernel when the range ends
-    // with one: it runs first and nothing before it touches the GRAD space)
+    // gradients of parameters that several ops share accumulate, and the direct fallback kernels (conv.h) add with float
+    // atomics: start from zero (cleared by the ELBO op's kernel when the range ends with one: it runs first and
+    // nothing before it touches the GRAD space)
     const bool zero_in_elbo = zero_grads && op_end > op_begin && ops[op_end - 1].kind == VAE_OP_ELBO;
     if (zero_grads && !zero_in_elbo) VAE_HIP(hipMemsetAsync(bases[2], 0, (size_t)base_sizes[2] * sizeof(float), c.s));
     for (int i = op_end - 1; i >= op_begin && rc == VAE_OK; --i) {

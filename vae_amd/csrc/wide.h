@@ -9,8 +9,9 @@
 //                       of conv.h: Conv forward + ConvT input gradient; TR: ConvT forward + Conv input gradient).
 //                       GEMM: D[channel][pixel], K = (ci, tap); transposed gathers run per output-parity class.
 //   wide_wgrad_k      : dw[a][c][kh][kw] += sum_{b,oh,ow} S[b,a,oh,ow] * G[b,c,oh*sh-ph+kh,ow*sw-pw+kw]
-//                       (= conv_wgrad_k).  GEMM: D[a][(c,tap)], K = pixels, split over grid.x, float atomics into
-//                       the zeroed dw (tens of adds per element: the matrices are large here).
+//                       (= conv_wgrad_k).  GEMM: D[a][(c,tap)], K = pixels, split over grid.x; every slice writes its
+//                       own copy of dw and wide_wgrad_reduce_k adds them in a fixed order (a caller that passes no
+//                       partial region gets float atomics into the zeroed dw: not bit-reproducible).
 #pragma once
 #include "common.h"
 #include "conv.h"
