@@ -281,6 +281,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    watchdog = None
+    if world > 1 and args.rank_timeout > 0:
+        # a rank started by somebody else's launcher (torchrun) has no parent of ours to end it: a collective that never
+        # completes must not hang the job for good
+        import threading
+
+        def _expired():
+            print(f"bench.py rank {rank}: not finished within --rank-timeout {args.rank_timeout}s (a collective that "
+                  "never completed?): exiting; try --dp-single-comm or VAE_BENCH_BACKEND=gloo", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.rank_timeout, _expired)
+        watchdog.daemon = True
+        watchdog.start()
     ngpu = max(torch.cuda.device_count(), 1)
     backend = os.environ.get("VAE_BENCH_BACKEND") or ("nccl" if ngpu >= world else "gloo")
     local_rank %= ngpu
@@ -393,6 +406,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, B)
         print(json.dumps(line), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         dist.destroy_process_group()
 
