@@ -946,6 +946,10 @@ static int scat_geom_sbr(const IgGeom& q, int* inst) {
     if (nj * 4 * TH_THREADS / CHW < sbr) sbr = nj * 4 * TH_THREADS / CHW;
     if (sbr < 1) return 0;
     while (sbr & (sbr - 1)) sbr &= sbr - 1;  // a power of two: batches usually are, and the rounds then deal out evenly
+    {   // (diagnostic: VAE_SCAT_SBR caps the samples per round)
+        static const int cap = [] { const char* e = getenv("VAE_SCAT_SBR"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 0; }();
+        if (cap > 0 && sbr > cap) sbr = cap;
+    }
     *inst = cls;
     return sbr;
 }
