@@ -77,12 +77,13 @@ def _mnist_case(B):
     return _ORACLE[B]
 
 
-@pytest.mark.parametrize("B,fc", [(4096, "0"), (4096, "1"), (16384, None), (16384, "1")],
-                         ids=["b4096_fc_off", "b4096_fc_on", "b16384_auto", "b16384_fc_on"])
+@pytest.mark.parametrize("B,fc", [(4096, "0"), (4096, "1"), (16384, None), (16384, "1"), (65536, None)],
+                         ids=["b4096_fc_off", "b4096_fc_on", "b16384_auto", "b16384_fc_on", "b65536_auto"])
 def test_mnist_parity_across_the_linear_path_switch(B, fc, monkeypatch):
     """The MNIST step against the oracle with the Linear/reparam run forced op by op and as fc_chain_k at the benched
     batch, and at B = 16,384, beyond FC_AUTO_MAX_BATCH, where the executor itself switches to the per-op Linear kernels
-    (and the conv kernels run other chunk plans); the environment variable is read at every run of a program."""
+    (and the conv kernels run other chunk plans), and at B = 65,536, the batch of bench.py's strong_scaling_ref and the
+    global batch of BASELINE configs[3]; the environment variable is read at every run of a program."""
     import vae_amd
     from vae_amd.train import FusedTrainStep
     if fc is None:

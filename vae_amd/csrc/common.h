@@ -81,7 +81,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ float wave_sum_all(float v) { return wave_sum(v); }
 
 // Sum over a 256-thread block; result valid in thread 0.  `sm` >= 4 floats of LDS.
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {

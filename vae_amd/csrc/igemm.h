@@ -861,7 +861,7 @@ __global__ __launch_bounds__(IG_THREADS) __attribute__((amdgpu_waves_per_eu(MT *
                 const float* row = img + u * rowlen;
                 float t = 0.f;
                 for (int i = lane; i < rowlen; i += 64) t += row[i];
-                t = wave_sum_all(t);
+                t = wave_sum(t);
                 const int c = u - (int)fdiv((uint32_t)u, a.d_bC) * C;
                 if (lane == c) bsum += t;
             }
