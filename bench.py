@@ -248,7 +248,7 @@ def roofline_step(stepper, iters, model_name):
                 "share_of_step": top["us_per_step"] / step_us,
                 "step_launches": len(acc), "step_sum_of_launches_us": step_us,
                 "families": [{"kernel": d["kernel"], "launches": d["launches_per_step"], "us_per_step": round(d["us_per_step"], 2),
-                              "GBps": round(d["bytes_per_step"] / (d["us_per_step"] * 1e-6) / 1e9, 1)} for d in order[:16]],
+                              "GBps": round(d["bytes_per_step"] / (d["us_per_step"] * 1e-6) / 1e9, 1)} for d in order[:int(os.environ.get("VAE_BENCH_FAMILIES", "16"))]],
                 "timing": f"HIP event behind every launch on the launch stream, {iters} eager train steps (vae_time_step)"})
     return out
 

@@ -44,8 +44,10 @@ def _build(B, K0, H, Lz, H2, N2, gen, two_branches=True, kl_grad=True):
     return b.build(), flat, offs, params, (x, mu, lv, z, y)
 
 
-def _run(prog, flat, bufs, xs, epss, dout, fc):
+def _run(prog, flat, bufs, xs, epss, dout, fc, ws_min_b=None):
     os.environ["VAE_AMD_FC"] = "1" if fc else "0"
+    if ws_min_b is not None:
+        os.environ["VAE_LINWS_MIN_B"] = str(ws_min_b)
     try:
         x, mu, lv, z, y = bufs
         work = prog.new_workspace(DEV)
@@ -62,6 +64,7 @@ def _run(prog, flat, bufs, xs, epss, dout, fc):
         return out
     finally:
         os.environ.pop("VAE_AMD_FC", None)
+        os.environ.pop("VAE_LINWS_MIN_B", None)
 
 
 @pytest.mark.parametrize("B,K0,H,Lz,H2,N2,two", [
@@ -103,3 +106,23 @@ def test_chain_equals_op_by_op_and_autograd(B, K0, H, Lz, H2, N2, two):
             continue  # the second branch does not exist in this program
         close(a["grads"][offs[id(w)]:offs[id(w)] + w.numel()].view_as(w), wt.grad, f"dW{i}")
         close(a["grads"][offs[id(b)]:offs[id(b)] + b.numel()], bt.grad, f"db{i}")
+
+
+@pytest.mark.parametrize("B,K0,H,Lz,H2,N2,two", [
+    (300, 288, 100, 16, 100, 288, True),    # the notebook model's shapes (latent 16: 16-byte rows); two column groups in d(x)
+    (777, 64, 48, 8, 52, 100, False),       # ragged last row tile, column tiles that are not full
+    (33, 32, 320, 4, 12, 36, True),         # 320 columns: two column groups forward; fewer rows than a CU has workgroups
+])
+def test_weights_stationary_linear_equals_the_tile_kernel(B, K0, H, Lz, H2, N2, two):
+    """lin_ws_k (large batches: a column group of W stays in LDS, 16-row tiles stream) against lin_fwd_k on the same
+    op-by-op program: forward values, input gradient, parameter gradients.  Different summation order: rtol 2e-5."""
+    gen = torch.Generator().manual_seed(B * 11 + K0)
+    prog, flat, offs, params, bufs = _build(B, K0, H, Lz, H2, N2, gen, two_branches=two)
+    xs = torch.randn(B, K0, generator=gen).to(DEV)
+    epss = torch.randn(B, Lz, generator=gen).to(DEV)
+    dout = torch.randn(B, N2, generator=gen).to(DEV)
+    a = _run(prog, flat, bufs, xs, epss, dout, fc=False, ws_min_b=1)
+    r = _run(prog, flat, bufs, xs, epss, dout, fc=False, ws_min_b=1 << 30)
+    for k in a:
+        ref = r[k]
+        torch.testing.assert_close(a[k], ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()), msg=lambda m, k=k: f"{k}: {m}")

@@ -8,5 +8,5 @@ m = (vae_amd.mnist_vae.VariationalAutoencoder(15) if model == "mnist" else vae_a
 opt = vae_amd.optim.Adam(m.parameters(), lr=1e-3)
 st = FusedTrainStep(m, opt, B, "cuda", use_graph=False)
 x = torch.rand(B, 1, 28, 28, device="cuda") if model == "mnist" else 50 + 10 * torch.randn(B, 3, 60, device="cuda")
-for i in range(3):
+for i in range(int(os.environ.get("STEPS", 3))):
     st.step(x); torch.cuda.synchronize(); print("---- step", i, flush=True)

@@ -16,6 +16,7 @@
 //                 row of the layer's partial region; wgrad_finalize_k adds the rows in a fixed order, so the
 //                 gradient is bit-identical from run to run (no float atomics).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "igemm.h"  // f32x4, FastDiv
 
@@ -192,6 +193,201 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
             *cp = a.accumulate ? *cp + v : v;
         }
     }
+}
+
+// ---- large batches: weights stay in LDS, rows stream ---------------------------------------------------------
+// lin_fwd_k re-stages a 32-column slice of W and its 32 rows of A per workgroup: at B = 65,536 the 100 -> 288 layer is
+// 18,432 one-shot workgroups that each wait out one load latency (0.8 TB/s, 115-150 us per launch; the Linear layers are
+// then 27 % of the MNIST step).  lin_ws_k keeps a column group of W' (all of K, <= 304 columns: 115 KB for 288 x 100)
+// in LDS for the whole kernel - one workgroup of 16 waves per CU - and walks 16-row tiles of A: the tile two... one ahead
+// is in flight in registers while the current one is multiplied (wave w owns the column tiles w, w + 16 and
+// shares every A operand read among them).  Same LinArgs and semantics as lin_fwd_k (second head, second K segment,
+// act' on load, bias + activation, accumulate); fp32, 16-byte aligned rows only (the host checks).
+//   LDS: Wl[k][NS] with NS = 16 or 48 (mod 64): the four k rows of an MFMA step hit disjoint bank quarters;
+//        Xl[16][XS] with XS / 4 odd: the sixteen rows of an A operand read hit sixteen different bank quads.
+// (16 waves: four per SIMD.  With 8 the k loop ran at half the matrix pipe's rate - 4-byte LDS operand reads reach their
+// rate only at ~4 waves per SIMD, MI355X_MICROARCH.md, LDS - and staging / epilogue had nothing to overlap with)
+#define LWS_THREADS 1024
+#define LWS_WAVES 16
+#define LWS_RT 16     // rows per tile
+#define LWS_MAXNT 2   // column tiles per wave: <= 32 tiles = 512 columns per group
+#define LWS_NJ 2      // float4 of a row tile per thread: 16 * Ktot / 4 <= 2048
+struct LinWsPlan {
+    int NC, NS, XS, ng1, ng2;  // columns per group (multiple of 16), strides, column groups of head 1 / head 2
+};
+__global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int Kt = a.K * a.nseg, K4 = a.K >> 2;
+    float* Wl = smem;               // [Kt][NS]
+    float* Xl = smem + Kt * p.NS;   // [16][XS]
+    const bool head2 = (int)blockIdx.y >= p.ng1;
+    const float* const Wh = head2 ? a.W2 : a.W;
+    const float* const biash = head2 ? a.bias2 : a.bias;
+    float* const Ch = head2 ? a.C2 : a.C;
+    const int Nh = head2 ? a.N2 : a.N, ldch = head2 ? a.ldc2 : a.ldc;
+    const int n0 = (head2 ? (int)blockIdx.y - p.ng1 : (int)blockIdx.y) * p.NC;
+    const int ncols = min(p.NC, Nh - n0);          // real columns of this group
+    const int ntile = (ncols + 15) >> 4;
+    const int ntiles_rows = (a.B + LWS_RT - 1) / LWS_RT, G = gridDim.x;
+
+    // ---- this thread's float4 slots of a row tile: slot e4 -> (segment, row, k)
+    int srow[LWS_NJ], sk[LWS_NJ], sseg[LWS_NJ];
+    bool sok[LWS_NJ];
+    const int nvec = LWS_RT * K4 * a.nseg;
+#pragma unroll
+    for (int j = 0; j < LWS_NJ; ++j) {
+        const int e = tid + LWS_THREADS * j;
+        sok[j] = e < nvec;
+        const int ec = sok[j] ? e : 0;
+        const int seg = ec / (LWS_RT * K4), e2 = ec - seg * LWS_RT * K4;
+        srow[j] = e2 / K4;
+        sk[j] = (e2 - srow[j] * K4) << 2;
+        sseg[j] = seg;
+    }
+    f32x4 xv[LWS_NJ], yv[LWS_NJ];
+    const bool hasy = a.A2 != nullptr;
+    auto load = [&](int t) __attribute__((always_inline)) {
+        const int r0 = t * LWS_RT;
+#pragma unroll
+        for (int j = 0; j < LWS_NJ; ++j) {
+            const int r = min(r0 + srow[j], a.B - 1);
+            const float* Ag = sseg[j] ? a.Ab : a.A;
+            xv[j] = *reinterpret_cast<const f32x4*>(Ag + (int64_t)r * a.lda + sk[j]);
+            if (hasy) {
+                const float* Yg = sseg[j] ? a.A2b : a.A2;
+                yv[j] = *reinterpret_cast<const f32x4*>(Yg + (int64_t)r * a.lda2 + sk[j]);
+            }
+        }
+    };
+    IG_TDECL;
+    IG_T();
+    if ((int)blockIdx.x < ntiles_rows) load(blockIdx.x);
+    IG_T();
+
+    // ---- the column group's weights, once: Wl[seg*K + k][n - n0] = W'(k, n)
+    {
+        const bool nfast = a.wsn == 1;
+        for (int seg = 0; seg < a.nseg; ++seg) {
+            const float* Wg = seg ? a.Wb : Wh;
+            if (nfast) {  // W'[k][n], n contiguous: a float4 is 4 columns of one k
+                const int c4 = p.NC >> 2;
+                for (int e = tid; e < a.K * c4; e += LWS_THREADS) {
+                    const int k = e / c4, n = (e - k * c4) << 2;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n0 + n < Nh) v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)k * a.wsk + n0 + n);  // (N % 4 == 0)
+                    *reinterpret_cast<f32x4*>(Wl + (seg * a.K + k) * p.NS + n) = v;
+                }
+            } else {      // W'[n][k], k contiguous: a float4 is 4 k of one column.  A wave instruction takes 16 columns x 4
+                          // groups of k: with 64 consecutive k of ONE column every lane's four LDS writes hit the same
+                          // bank (the row stride is 0 mod 16 banks x 4): 8-10 us of staging per workgroup
+                for (int e = tid; e < p.NC * K4; e += LWS_THREADS) {
+                    const int r = e >> 4, nt = r / K4;
+                    const int n = nt * 16 + (e & 15), k = (r - nt * K4) << 2;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n0 + n < Nh) v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)(n0 + n) * a.wsn + k);
+                    float* d = Wl + (seg * a.K + k) * p.NS + n;
+                    d[0] = v[0]; d[p.NS] = v[1]; d[2 * p.NS] = v[2]; d[3 * p.NS] = v[3];
+                }
+            }
+        }
+    }
+    float bias_r[LWS_MAXNT];
+#pragma unroll
+    for (int i = 0; i < LWS_MAXNT; ++i) {
+        const int n = n0 + (wid + LWS_WAVES * i) * 16 + li;
+        bias_r[i] = (biash != nullptr && n < Nh) ? biash[n] : 0.f;
+    }
+    const float* ap = Xl + li * p.XS + lk;
+    const float* wp = Wl + lk * p.NS + li;
+    const int ksteps = Kt >> 2;
+    const int nmy = wid < ntile ? (ntile - wid + LWS_WAVES - 1) / LWS_WAVES : 0;  // column tiles of this wave
+    IG_T();
+
+    for (int t = blockIdx.x; t < ntiles_rows; t += G) {
+        IG_T();
+        lds_barrier();  // the previous tile's operand reads are done (first round: nothing).  (LDS-only barriers: __syncthreads()
+                        // would also wait for the prefetch just issued and the epilogue's stores, a load latency per tile)
+#pragma unroll
+        for (int j = 0; j < LWS_NJ; ++j) {
+            if (!sok[j]) continue;
+            f32x4 v = xv[j];
+            if (hasy) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] *= act_grad_from_out(yv[j][u], a.a_act, a.a_slope);
+            }
+            *reinterpret_cast<f32x4*>(Xl + srow[j] * p.XS + sseg[j] * a.K + sk[j]) = v;
+        }
+        if (t + G < ntiles_rows) load(t + G);
+        IG_T();
+        lds_barrier();  // the tile (first round: also the weights) is staged
+        IG_T();
+        f32x4 acc[LWS_MAXNT];
+#pragma unroll
+        for (int i = 0; i < LWS_MAXNT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (one loop per count of column tiles this wave owns: a test inside the k loop is a branch per MFMA)
+        auto kloop = [&](auto cnt) __attribute__((always_inline)) {
+            constexpr int NT = decltype(cnt)::value;
+            // U k-steps per group, two register sets: the operand reads of group g + 1 are issued BEFORE the MFMAs of
+            // group g (a wave's MFMAs queue on the matrix pipe, and nothing behind them in its instruction stream
+            // issues meanwhile: with the reads behind them every group began with an exposed LDS latency, 120 cycles
+            // per MFMA and wave)
+            constexpr int U = 4;
+            float av[2][U], bv[2][U][NT];
+            const int ngroups = ksteps / U;
+            auto fetch = [&](int g, int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    av[set][u] = ap[4 * (g * U + u)];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) bv[set][u][i] = wp[4 * (g * U + u) * p.NS + (wid + LWS_WAVES * i) * 16];
+                }
+            };
+            auto fma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][u], bv[set][u][i], acc[i], 0, 0, 0);
+            };
+            if (ngroups > 0) fetch(0, 0);
+            int g = 0;
+            for (; g + 2 <= ngroups; g += 2) {
+                fetch(g + 1, 1);
+                fma(0);
+                if (g + 2 < ngroups) fetch(g + 2, 0);
+                fma(1);
+            }
+            if (g < ngroups) fma(0);
+            for (int s = ngroups * U; s < ksteps; ++s) {
+                const float a1 = ap[4 * s];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wp[4 * s * p.NS + (wid + LWS_WAVES * i) * 16], acc[i], 0, 0, 0);
+            }
+        };
+        if (nmy == 2) kloop(std::integral_constant<int, 2>{});
+        else if (nmy == 1) kloop(std::integral_constant<int, 1>{});
+        IG_T();
+        // D: row = lk*4 + r (sample), column = li
+        const int r0 = t * LWS_RT;
+#pragma unroll
+        for (int i = 0; i < LWS_MAXNT; ++i) {
+            const int n = n0 + (wid + LWS_WAVES * i) * 16 + li;
+            if (wid + LWS_WAVES * i >= ntile || n >= Nh) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = r0 + lk * 4 + r;
+                if (m < a.B) {
+                    float v = act_apply(acc[i][r] + bias_r[i], a.act, a.slope);
+                    float* cp = Ch + (int64_t)m * ldch + n;
+                    if (a.accumulate) v += *cp;  // (uniform)
+                    *cp = v;
+                }
+            }
+        }
+    }
+    IG_TPRINT("lin_ws: load0 | W staging | per tile: (epilogue) [barrier] stage+load [barrier] k-loop ...");
 }
 
 // ---- weight / bias gradient ----------------------------------------------------------------

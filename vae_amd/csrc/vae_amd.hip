@@ -1626,6 +1626,19 @@ static int bn_backward(const Ctx& c, const vae_op& op) {
 }
 
 // ---- linear ---------------------------------------------------------------------------------
+// dynamic LDS beyond 64 KiB has to be granted per kernel, once per device
+static int lin_ws_grant_lds() {
+    static bool done[64];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    VAE_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) VAE_FAIL(VAE_EINVAL, "device index %d out of range", dev);
+    if (done[dev]) return VAE_OK;
+    VAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lin_ws_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done[dev] = true;
+    return VAE_OK;
+}
 static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     if (a.B < 1 || a.N < 1 || a.K < 1) VAE_FAIL(VAE_EINVAL, "%s: bad shape %dx%dx%d", what, a.B, a.N, a.K);
     const int K16 = (a.K + 15) / 16 * 16;
@@ -1648,6 +1661,39 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
         vec = vec && al16(a.W2) && (a.wsn != 1 || a.N2 % 4 == 0);
         a.ny1 = ny;
         ny += (a.N2 + LIN_BN - 1) / LIN_BN;
+    }
+    // large batches: the weights stay in LDS and the rows stream (lin.h: lin_ws_k)
+    const int ws_min_b = [] { const char* e = getenv("VAE_LINWS_MIN_B"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 8192; }();  // (read at every launch: the tests switch it)
+    if (!g_bf16 && vec && a.B >= ws_min_b) {
+        LinWsPlan p;
+        const int Kt = a.K * a.nseg;
+        p.XS = Kt;
+        if (((p.XS >> 2) & 1) == 0) p.XS += 4;
+        const int budget = 40960 - 64 - LWS_RT * p.XS;  // floats of the 160 KiB
+        const int Nmax = a.W2 != nullptr && a.N2 > a.N ? a.N2 : a.N;
+        bool fits = LWS_RT * (Kt >> 2) <= LWS_THREADS * LWS_NJ;
+        p.NC = p.NS = 0;
+        for (int g = 1; fits && g <= 16; ++g) {
+            int nc = ((Nmax + g - 1) / g + 15) & ~15, ns = nc;
+            while ((ns & 63) != 16 && (ns & 63) != 48) ns += 16;
+            if ((int64_t)ns * Kt <= budget && nc <= 16 * LWS_WAVES * LWS_MAXNT) { p.NC = nc; p.NS = ns; break; }
+        }
+        if (fits && p.NC > 0) {
+            int rc = lin_ws_grant_lds();
+            if (rc) return rc;
+            p.ng1 = (a.N + p.NC - 1) / p.NC;
+            p.ng2 = a.W2 != nullptr ? (a.N2 + p.NC - 1) / p.NC : 0;
+            const int rtiles = (a.B + LWS_RT - 1) / LWS_RT;
+            int gx = 256 / (p.ng1 + p.ng2);  // one workgroup per CU: its weights fill the LDS
+            if (gx < 1) gx = 1;
+            if (gx > rtiles) gx = rtiles;
+            const size_t wbytes = ((size_t)Kt * p.NS + (size_t)LWS_RT * p.XS) * sizeof(float);
+            hipLaunchKernelGGL(lin_ws_k, dim3(gx, p.ng1 + p.ng2), dim3(LWS_THREADS), wbytes, c.s, a, p);
+            VAE_TNAME("lin_ws_k");
+            VAE_TBYTES(4.0 * ((double)a.B * ((double)a.K * a.nseg * (a.A2 != nullptr ? 2 : 1) + a.N + a.N2) + (double)a.K * a.nseg * (a.N + a.N2)));
+            VAE_LAUNCH_CHECK(what);
+            return VAE_OK;
+        }
     }
     const size_t bytes = (size_t)(LIN_BM * a.Kp + a.KC * LIN_WS) * sizeof(float);
     dim3 grid((a.B + LIN_BM - 1) / LIN_BM, ny);
