@@ -126,3 +126,25 @@ def test_weights_stationary_linear_equals_the_tile_kernel(B, K0, H, Lz, H2, N2, 
     for k in a:
         ref = r[k]
         torch.testing.assert_close(a[k], ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()), msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("B,K0,H,Lz,H2,N2,two", [
+    (300, 288, 100, 16, 100, 288, True),    # the notebook model's shapes: 18 x 7 and 7 x 18 accumulator tiles
+    (37, 51, 37, 7, 23, 45, True),          # nothing a multiple of 4 (scalar staging), a ragged only chunk
+    (200, 64, 320, 4, 12, 36, False),       # 20 tiles in the split dimension, several chunks per slice is not reached: 4 slices
+])
+def test_whole_layer_weight_gradient_equals_the_tile_kernel(B, K0, H, Lz, H2, N2, two, monkeypatch):
+    """lin_wgrad2_k (one workgroup owns a layer's whole dW for its batch slice; default from B = 8192) forced on at small
+    batches against lin_wgrad_k: parameter gradients of every Linear layer.  Different summation order: rtol 2e-5."""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VAE_AMD_LINWG2", mode)  # (sizes the partial regions at build time and picks the kernel at run time)
+        gen = torch.Generator().manual_seed(B * 13 + K0)
+        prog, flat, offs, params, bufs = _build(B, K0, H, Lz, H2, N2, gen, two_branches=two)
+        xs = torch.randn(B, K0, generator=gen).to(DEV)
+        epss = torch.randn(B, Lz, generator=gen).to(DEV)
+        dout = torch.randn(B, N2, generator=gen).to(DEV)
+        res[mode] = _run(prog, flat, bufs, xs, epss, dout, fc=False)
+    for k in res["1"]:
+        ref = res["0"][k]
+        torch.testing.assert_close(res["1"][k], ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()), msg=lambda m, k=k: f"{k}: {m}")

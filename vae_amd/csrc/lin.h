@@ -567,3 +567,161 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
         }
     }
 }
+
+// ---- weight / bias gradient, whole layer per workgroup (round 3) ----------------------------------------------------
+// lin_wgrad_k gives a workgroup a 64 x 64 tile of dW: X is re-read once per 64 output rows and dY once per 64
+// columns (129 MB through L2 for 25 MB of activations at B = 4096).  Here ONE workgroup of 16 waves owns the whole
+// dW[N][K] of a layer for its batch slice - up to 32 x 7 accumulator tiles spread over the waves, at most 14 per wave -
+// so every row of dY, Y and X is read exactly once: a 64-row chunk goes to LDS as it lies in memory ([b][n] and [b][k]
+// are the MFMA's A and B operands with the batch as the reduction index), 16 k-steps run on it, next chunk.  The
+// larger of the two tile counts is split over the waves (tiles w, w + 16), the smaller (<= 7) is walked by every wave.
+// Partial rows [slice][N*K + N] as before; wgrad_finalize_k sums them in a fixed order.
+#define LW2_THREADS 1024
+#define LW2_WAVES 16
+#define LW2_RB 64     // == LW_BB: the slices of both kernels are whole 64-row chunks
+#define LW2_FULLMAX 7
+__host__ __device__ inline int lw2_stride(int cols) {  // >= cols, = 16 (mod 32): the four batch rows of an MFMA step hit disjoint banks
+    int s = (cols + 15) & ~15;
+    if ((s & 31) != 16) s += 16;
+    return s;
+}
+__host__ __device__ inline int lw2_fullc(int t) { return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : LW2_FULLMAX; }
+
+template <bool SPLIT_N, int TFC>
+__device__ __forceinline__ void lw2_body(const LinWgArgs& a, int slice, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int TN = (a.N + 15) >> 4, TK = (a.K + 15) >> 4;
+    const int NS = lw2_stride(SPLIT_N ? a.N : 16 * TFC), KS = lw2_stride(SPLIT_N ? 16 * TFC : a.K);
+    float* Yl = smem;                 // dY' chunk [64][NS]
+    float* Xl = smem + LW2_RB * NS;   // X chunk   [64][KS]
+    const int TS = SPLIT_N ? TN : TK;
+    const int nsp = wid < TS ? (TS - wid + LW2_WAVES - 1) / LW2_WAVES : 0;  // split-dimension tiles of this wave (<= 2)
+    f32x4 acc[2][TFC];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TFC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool has_act = a.act != VAE_ACT_NONE, vec = a.vec != 0;
+    const int nchunks = (a.B + LW2_RB - 1) / LW2_RB;
+    const int c_first = slice * a.chunks_per_block, c_end = min(c_first + a.chunks_per_block, nchunks);
+    // the pad columns (and whatever a TFC wider than the layer reads) stay zero: staging writes real columns only
+    for (int e = tid; e < LW2_RB * (NS + KS); e += LW2_THREADS) smem[e] = 0.f;
+
+    for (int ch = c_first; ch < c_end; ++ch) {
+        const int b0 = ch * LW2_RB;
+        __syncthreads();  // the zeroes / the previous chunk's operand reads are done
+        if (vec) {
+            auto stage = [&](const float* src, const float* src2, int ld, int ld2, int cols, float* dst, int stride) __attribute__((always_inline)) {
+                const int c4 = cols >> 2, total = LW2_RB * c4;
+                for (int base = tid; base < total; base += 4 * LW2_THREADS) {
+                    f32x4 v[4], y[4];
+                    int rr[4], cc[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {  // every load unconditional with a clamped address
+                        const int e = min(base + j * LW2_THREADS, total - 1);
+                        rr[j] = e / c4;
+                        cc[j] = (e - rr[j] * c4) << 2;
+                        const int gr = min(b0 + rr[j], a.B - 1);
+                        v[j] = *reinterpret_cast<const f32x4*>(src + (int64_t)gr * ld + cc[j]);
+                        if (src2 != nullptr) y[j] = *reinterpret_cast<const f32x4*>(src2 + (int64_t)gr * ld2 + cc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (base + j * LW2_THREADS >= total) continue;
+                        f32x4 o = v[j];
+                        if (src2 != nullptr) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) o[u] *= act_grad_from_out(y[j][u], a.act, a.slope);
+                        }
+                        if (b0 + rr[j] >= a.B) o = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the batch add nothing
+                        *reinterpret_cast<f32x4*>(dst + rr[j] * stride + cc[j]) = o;
+                    }
+                }
+            };
+            stage(a.dY, has_act ? a.Y : nullptr, a.lddy, a.ldy, a.N, Yl, NS);
+            stage(a.X, nullptr, a.ldx, 0, a.K, Xl, KS);
+        } else {
+            for (int e = tid; e < LW2_RB * a.N; e += LW2_THREADS) {
+                const int r = e / a.N, c = e - r * a.N;
+                float v = 0.f;
+                if (b0 + r < a.B) {
+                    v = a.dY[(int64_t)(b0 + r) * a.lddy + c];
+                    if (has_act) v *= act_grad_from_out(a.Y[(int64_t)(b0 + r) * a.ldy + c], a.act, a.slope);
+                }
+                Yl[r * NS + c] = v;
+            }
+            for (int e = tid; e < LW2_RB * a.K; e += LW2_THREADS) {
+                const int r = e / a.K, c = e - r * a.K;
+                Xl[r * KS + c] = b0 + r < a.B ? a.X[(int64_t)(b0 + r) * a.ldx + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (a.db != nullptr && tid < a.N) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < LW2_RB; ++r) t += Yl[r * NS + tid];
+            bsum += t;
+        }
+        // D[n][k] += sum_b dY'[b][n] * X[b][k]: A = Yl (row n = li, reduction index b = lk), B = Xl (b = lk, column k = li)
+        auto kloop = [&](auto cnt) __attribute__((always_inline)) {
+            constexpr int NSP = decltype(cnt)::value;
+            const float* sp = (SPLIT_N ? Yl : Xl) + lk * (SPLIT_N ? NS : KS) + wid * 16 + li;  // split operand, tile wid (+16 tiles)
+            const float* fp = (SPLIT_N ? Xl : Yl) + lk * (SPLIT_N ? KS : NS) + li;             // full operand, tiles 0..TFC-1
+            const int sst = 4 * (SPLIT_N ? NS : KS), fst = 4 * (SPLIT_N ? KS : NS);
+#pragma unroll 2
+            for (int s = 0; s < LW2_RB / 4; ++s) {
+                float sv[NSP], fv[TFC];
+#pragma unroll
+                for (int i = 0; i < NSP; ++i) sv[i] = sp[s * sst + i * 16 * LW2_WAVES];
+#pragma unroll
+                for (int j = 0; j < TFC; ++j) fv[j] = fp[s * fst + j * 16];
+#pragma unroll
+                for (int i = 0; i < NSP; ++i)
+#pragma unroll
+                    for (int j = 0; j < TFC; ++j)
+                        acc[i][j] = SPLIT_N ? __builtin_amdgcn_mfma_f32_16x16x4f32(sv[i], fv[j], acc[i][j], 0, 0, 0)
+                                            : __builtin_amdgcn_mfma_f32_16x16x4f32(fv[j], sv[i], acc[i][j], 0, 0, 0);
+            }
+        };
+        if (nsp == 2) kloop(std::integral_constant<int, 2>{});
+        else if (nsp == 1) kloop(std::integral_constant<int, 1>{});
+    }
+    float* const prow = a.part + (int64_t)slice * ((int64_t)a.N * a.K + a.N);
+    if (a.db != nullptr && tid < a.N) prow[(int64_t)a.N * a.K + tid] = bsum;
+    // D: row (n) = lk*4 + r, column (k) = li
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i >= nsp) continue;
+#pragma unroll
+        for (int j = 0; j < TFC; ++j) {
+            const int nt = SPLIT_N ? wid + i * LW2_WAVES : j, kt = SPLIT_N ? j : wid + i * LW2_WAVES;
+            const int k = kt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nt * 16 + lk * 4 + r;
+                if (n < a.N && k < a.K) prow[(int64_t)n * a.K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LW2_THREADS) void lin_wgrad2_k(LinWgMulti m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < LIN_WG_MAX_LAYERS; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.l[i].first_block) layer = i;
+    const LinWgArgs& a = m.l[layer];
+    const int slice = blockIdx.x - a.first_block;
+    const int TN = (a.N + 15) >> 4, TK = (a.K + 15) >> 4;
+    const bool split_n = TN >= TK;
+    const int tfc = lw2_fullc(split_n ? TK : TN);
+#define LW2_CASE(SN, T) lw2_body<SN, T>(a, slice, smem)
+    if (split_n) {
+        if (tfc == 1) LW2_CASE(true, 1); else if (tfc == 2) LW2_CASE(true, 2); else if (tfc == 4) LW2_CASE(true, 4); else LW2_CASE(true, LW2_FULLMAX);
+    } else {
+        if (tfc == 1) LW2_CASE(false, 1); else if (tfc == 2) LW2_CASE(false, 2); else if (tfc == 4) LW2_CASE(false, 4); else LW2_CASE(false, LW2_FULLMAX);
+    }
+#undef LW2_CASE
+}

@@ -1713,12 +1713,34 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
 // Batch slices of a Linear weight gradient: ~512 workgroups per layer (all layers share one launch); every slice
 // owns a row of the layer's partial region.
 struct LinWgPlan { int gx, gy, gz, chunks_per_block; };
+// the whole-layer kernel (lin.h: lin_wgrad2_k) takes a layer whose smaller tile count is <= 7 and larger <= 32
+static bool lin_wgrad2_shape_ok(int N, int K) {
+    const int TN = (N + 15) / 16, TK = (K + 15) / 16;
+    const int lo = TN < TK ? TN : TK, hi = TN < TK ? TK : TN;
+    if (lo > LW2_FULLMAX || hi > 2 * LW2_WAVES) return false;
+    const bool split_n = TN >= TK;
+    const int tfc = lw2_fullc(lo);
+    const int NS = lw2_stride(split_n ? N : 16 * tfc), KS = lw2_stride(split_n ? 16 * tfc : K);
+    return (int64_t)LW2_RB * (NS + KS) <= 40000;  // floats of the 160 KiB
+}
+// ... from B = 8192: below, a slice is one 64-row chunk per workgroup whose 173 KB of rows and 115 KB partial row go
+// through ONE CU's load / store path (~10 B/clk): 29.7 us against the tile kernel's 31.8 at B = 4096, and the finalize
+// launch reads twice the rows.  At B = 65,536: 407 -> 254 us.  VAE_AMD_LINWG2 = 0 / 1 forces it off / on at any batch.
+static bool lin_wgrad2_enabled(int B) {
+    // (read at every call - the tests switch it; it must not change between sizing a program's partial regions and running it)
+    const char* e = getenv("VAE_AMD_LINWG2");
+    const int mode = (e != nullptr && *e) ? (atoi(e) != 0 ? 1 : 0) : -1;
+    return mode < 0 ? B >= 8192 : mode == 1;
+}
 static LinWgPlan lin_wgrad_plan(int B, int N, int K) {
     LinWgPlan p;
     const int tiles = ((N + LW_BN - 1) / LW_BN) * ((K + 63) / 64);
     const int nch = (B + LW_BB - 1) / LW_BB;
     static const int target = [] { const char* e = getenv("VAE_LINWG_TARGET"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 512; }();
     int gx = (target + tiles - 1) / tiles;
+    // (shapes the whole-layer kernel takes: one workgroup per slice, so the slices are what fills the GPU: one 64-row
+    // chunk each up to 128 of them.  The tile kernel runs on the same slices when it has to, e.g. in bf16 mode)
+    if (lin_wgrad2_enabled(B) && lin_wgrad2_shape_ok(N, K)) gx = 128;
     if (gx > nch) gx = nch;
     p.chunks_per_block = (nch + gx - 1) / gx;
     p.gx = (nch + p.chunks_per_block - 1) / p.chunks_per_block;
@@ -1734,21 +1756,55 @@ extern "C" int64_t vae_linear_wgrad_partial_floats(const vae_op* op, int B) {
 // (Measured and dropped in round 3: this launch on a side stream / graph branch beside the encoder's convolution
 // backward, forked behind the Linear run's input gradients and joined before wgrad_finalize_k: 0.508 -> 0.513 ms/step.
 // Like the conv weight gradients in round 1, kernels that each fill the CUs only take turns.)
+static int lin_wgrad2_grant_lds() {  // dynamic LDS beyond 64 KiB: once per device
+    static bool done[64];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    VAE_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) VAE_FAIL(VAE_EINVAL, "device index %d out of range", dev);
+    if (done[dev]) return VAE_OK;
+    VAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lin_wgrad2_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done[dev] = true;
+    return VAE_OK;
+}
 static int flush_linear_wgrads(const Ctx& c) {
     LinWgMulti& m = c.lin_wg;
     if (m.n == 0) return VAE_OK;
     int blocks = 0;
-    for (int i = 0; i < m.n; ++i) {
-        m.l[i].first_block = blocks;
-        blocks += m.l[i].gx * m.l[i].gy * m.l[i].gz;
+    bool v2 = !g_bf16 && m.n > 0 && lin_wgrad2_enabled(m.l[0].B);
+    size_t lds2 = 0;
+    for (int i = 0; i < m.n && v2; ++i) {
+        const LinWgArgs& a = m.l[i];
+        if (!lin_wgrad2_shape_ok(a.N, a.K)) { v2 = false; break; }
+        const int TN = (a.N + 15) / 16, TK = (a.K + 15) / 16;
+        const bool split_n = TN >= TK;
+        const int tfc = lw2_fullc(split_n ? TK : TN);
+        const size_t fl = (size_t)LW2_RB * (lw2_stride(split_n ? a.N : 16 * tfc) + lw2_stride(split_n ? 16 * tfc : a.K));
+        if (fl > lds2) lds2 = fl;
     }
-    if (g_bf16) hipLaunchKernelGGL(lin_wgrad_k<true>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
-    else hipLaunchKernelGGL(lin_wgrad_k<false>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    if (v2) {  // one workgroup per (layer, batch slice)
+        int rc = lin_wgrad2_grant_lds();
+        if (rc) return rc;
+        for (int i = 0; i < m.n; ++i) {
+            m.l[i].first_block = blocks;
+            blocks += m.l[i].gx;
+        }
+        hipLaunchKernelGGL(lin_wgrad2_k, dim3(blocks), dim3(LW2_THREADS), lds2 * sizeof(float), c.s, m);
+    } else {
+        for (int i = 0; i < m.n; ++i) {
+            m.l[i].first_block = blocks;
+            blocks += m.l[i].gx * m.l[i].gy * m.l[i].gz;
+        }
+        if (g_bf16) hipLaunchKernelGGL(lin_wgrad_k<true>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+        else hipLaunchKernelGGL(lin_wgrad_k<false>, dim3(blocks), dim3(LIN_THREADS), 0, c.s, m);
+    }
     if (vae_tl_timer != nullptr) {
         double fl = 0;
         for (int i = 0; i < m.n; ++i)
             fl += (double)m.l[i].B * (m.l[i].K + (m.l[i].act != VAE_ACT_NONE ? 2.0 : 1.0) * m.l[i].N) + (double)m.l[i].gx * ((double)m.l[i].N * m.l[i].K + m.l[i].N);
-        VAE_TNAME("lin_wgrad_k<%s>", g_bf16 ? "true" : "false");
+        if (v2) VAE_TNAME("lin_wgrad2_k");
+        else VAE_TNAME("lin_wgrad_k<%s>", g_bf16 ? "true" : "false");
         VAE_TBYTES(4.0 * fl);
     }
     m.n = 0;
