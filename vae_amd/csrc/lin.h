@@ -203,8 +203,6 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
 // is in flight in registers while the current one is multiplied (wave w owns the column tiles w, w + 16 and
 // shares every A operand read among them).  Same LinArgs and semantics as lin_fwd_k (second head, second K segment,
 // act' on load, bias + activation, accumulate); fp32, 16-byte aligned rows only (the host checks).
-//   LDS: Wl[k][NS] with NS = 16 or 48 (mod 64): the four k rows of an MFMA step hit disjoint bank quarters;
-//        Xl[16][XS] with XS / 4 odd: the sixteen rows of an A operand read hit sixteen different bank quads.
 // (16 waves: four per SIMD.  With 8 the k loop ran at half the matrix pipe's rate - 4-byte LDS operand reads reach their
 // rate only at ~4 waves per SIMD, MI355X_MICROARCH.md, LDS - and staging / epilogue had nothing to overlap with)
 #define LWS_THREADS 1024
@@ -213,14 +211,21 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_fwd_k(LinArgs a) {
 #define LWS_MAXNT 2   // column tiles per wave: <= 32 tiles = 512 columns per group
 #define LWS_NJ 2      // float4 of a row tile per thread: 16 * Ktot / 4 <= 2048
 struct LinWsPlan {
-    int NC, NS, XS, ng1, ng2;  // columns per group (multiple of 16), strides, column groups of head 1 / head 2
+    int NC, S4, PW, PX, ng1, ng2;  // columns per group (multiple of 16); floats per (column | row) of one k-residue plane
+                                   // (4 * odd >= k-steps rounded up to 4); plane sizes (multiples of 64 floats); column
+                                   // groups of head 1 / head 2
 };
+// LDS: operands are laid out for 16-byte reads of FOUR consecutive k-steps: the lane (lk, li) of an MFMA step s reads
+// k = 4 s + lk, so k-residue lk gets a plane of its own, Wl[lk][n][s] and Xl[lk][row][s] with s contiguous.  Row stride
+// S4 = 4 * odd floats and planes that are multiples of 64 floats: the sixteen lanes of a ds_read_b128 group (all one
+// residue) hit sixteen different 16-byte bank groups.  4-byte operand reads (one per lane and k-step) ran the k loop at
+// half the matrix pipe's rate.  k-steps past the real ones are zero in both images.
 __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int Kt = a.K * a.nseg, K4 = a.K >> 2;
-    float* Wl = smem;               // [Kt][NS]
-    float* Xl = smem + Kt * p.NS;   // [16][XS]
+    float* Wl = smem;               // [4][NC][S4] (planes PW apart)
+    float* Xl = smem + 4 * p.PW;    // [4][16][S4] (planes PX apart)
     const bool head2 = (int)blockIdx.y >= p.ng1;
     const float* const Wh = head2 ? a.W2 : a.W;
     const float* const biash = head2 ? a.bias2 : a.bias;
@@ -230,9 +235,11 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
     const int ncols = min(p.NC, Nh - n0);          // real columns of this group
     const int ntile = (ncols + 15) >> 4;
     const int ntiles_rows = (a.B + LWS_RT - 1) / LWS_RT, G = gridDim.x;
+    IG_TDECL;
+    IG_T();
 
-    // ---- this thread's float4 slots of a row tile: slot e4 -> (segment, row, k)
-    int srow[LWS_NJ], sk[LWS_NJ], sseg[LWS_NJ];
+    // ---- this thread's float4 slots of a row tile: slot e4 -> (segment, row, k); a float4 is one k-step (k = 4 s + 0..3)
+    int srow[LWS_NJ], sdst[LWS_NJ], sk[LWS_NJ], sseg[LWS_NJ];
     bool sok[LWS_NJ];
     const int nvec = LWS_RT * K4 * a.nseg;
 #pragma unroll
@@ -244,6 +251,7 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
         srow[j] = e2 / K4;
         sk[j] = (e2 - srow[j] * K4) << 2;
         sseg[j] = seg;
+        sdst[j] = srow[j] * p.S4 + ((seg * a.K + sk[j]) >> 2);  // + lk * PX per component
     }
     f32x4 xv[LWS_NJ], yv[LWS_NJ];
     const bool hasy = a.A2 != nullptr;
@@ -260,12 +268,13 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
             }
         }
     };
-    IG_TDECL;
-    IG_T();
     if ((int)blockIdx.x < ntiles_rows) load(blockIdx.x);
     IG_T();
 
-    // ---- the column group's weights, once: Wl[seg*K + k][n - n0] = W'(k, n)
+    // ---- both images start as zeroes (the k-steps past Kt / 4, the columns past the real ones)
+    for (int e = tid; e < 4 * (p.PW + p.PX); e += LWS_THREADS) smem[e] = 0.f;
+    __syncthreads();
+    // ---- the column group's weights, once: Wl[k & 3][n - n0][k >> 2] = W'(k, n), k counted over the segments
     {
         const bool nfast = a.wsn == 1;
         for (int seg = 0; seg < a.nseg; ++seg) {
@@ -274,20 +283,23 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
                 const int c4 = p.NC >> 2;
                 for (int e = tid; e < a.K * c4; e += LWS_THREADS) {
                     const int k = e / c4, n = (e - k * c4) << 2;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (n0 + n < Nh) v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)k * a.wsk + n0 + n);  // (N % 4 == 0)
-                    *reinterpret_cast<f32x4*>(Wl + (seg * a.K + k) * p.NS + n) = v;
+                    if (n0 + n < Nh) {  // (N % 4 == 0)
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)k * a.wsk + n0 + n);
+                        const int kk = seg * a.K + k;
+                        float* d = Wl + (kk & 3) * p.PW + n * p.S4 + (kk >> 2);
+                        d[0] = v[0]; d[p.S4] = v[1]; d[2 * p.S4] = v[2]; d[3 * p.S4] = v[3];
+                    }
                 }
-            } else {      // W'[n][k], k contiguous: a float4 is 4 k of one column.  A wave instruction takes 16 columns x 4
-                          // groups of k: with 64 consecutive k of ONE column every lane's four LDS writes hit the same
-                          // bank (the row stride is 0 mod 16 banks x 4): 8-10 us of staging per workgroup
+            } else {      // W'[n][k], k contiguous: a float4 is one k-step of one column; a wave instruction takes 16
+                          // columns x 4 k-steps
                 for (int e = tid; e < p.NC * K4; e += LWS_THREADS) {
                     const int r = e >> 4, nt = r / K4;
                     const int n = nt * 16 + (e & 15), k = (r - nt * K4) << 2;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (n0 + n < Nh) v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)(n0 + n) * a.wsn + k);
-                    float* d = Wl + (seg * a.K + k) * p.NS + n;
-                    d[0] = v[0]; d[p.NS] = v[1]; d[2 * p.NS] = v[2]; d[3 * p.NS] = v[3];
+                    if (n0 + n < Nh) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(Wg + (int64_t)(n0 + n) * a.wsn + k);
+                        float* d = Wl + n * p.S4 + ((seg * a.K + k) >> 2);
+                        d[0] = v[0]; d[p.PW] = v[1]; d[2 * p.PW] = v[2]; d[3 * p.PW] = v[3];
+                    }
                 }
             }
         }
@@ -298,9 +310,9 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
         const int n = n0 + (wid + LWS_WAVES * i) * 16 + li;
         bias_r[i] = (biash != nullptr && n < Nh) ? biash[n] : 0.f;
     }
-    const float* ap = Xl + li * p.XS + lk;
-    const float* wp = Wl + lk * p.NS + li;
-    const int ksteps = Kt >> 2;
+    const float* ap = Xl + lk * p.PX + li * p.S4;
+    const float* wp = Wl + lk * p.PW + (wid * 16 + li) * p.S4;
+    const int ngroups = ((Kt >> 2) + 3) >> 2;  // groups of four k-steps (the last one padded with zeroes)
     const int nmy = wid < ntile ? (ntile - wid + LWS_WAVES - 1) / LWS_WAVES : 0;  // column tiles of this wave
     IG_T();
 
@@ -316,7 +328,8 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] *= act_grad_from_out(yv[j][u], a.a_act, a.a_slope);
             }
-            *reinterpret_cast<f32x4*>(Xl + srow[j] * p.XS + sseg[j] * a.K + sk[j]) = v;
+            float* d = Xl + sdst[j];
+            d[0] = v[0]; d[p.PX] = v[1]; d[2 * p.PX] = v[2]; d[3 * p.PX] = v[3];
         }
         if (t + G < ntiles_rows) load(t + G);
         IG_T();
@@ -328,29 +341,22 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
         // (one loop per count of column tiles this wave owns: a test inside the k loop is a branch per MFMA)
         auto kloop = [&](auto cnt) __attribute__((always_inline)) {
             constexpr int NT = decltype(cnt)::value;
-            // U k-steps per group, two register sets: the operand reads of group g + 1 are issued BEFORE the MFMAs of
-            // group g (a wave's MFMAs queue on the matrix pipe, and nothing behind them in its instruction stream
-            // issues meanwhile: with the reads behind them every group began with an exposed LDS latency, 120 cycles
-            // per MFMA and wave)
-            constexpr int U = 4;
-            float av[2][U], bv[2][U][NT];
-            const int ngroups = ksteps / U;
+            // two register sets: the operand reads of group g + 1 are issued BEFORE the MFMAs of group g (a wave's
+            // MFMAs queue on the matrix pipe, and nothing behind them in its instruction stream issues meanwhile)
+            f32x4 av[2], bv[2][NT];
             auto fetch = [&](int g, int set) __attribute__((always_inline)) {
+                av[set] = *reinterpret_cast<const f32x4*>(ap + 4 * g);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    av[set][u] = ap[4 * (g * U + u)];
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) bv[set][u][i] = wp[4 * (g * U + u) * p.NS + (wid + LWS_WAVES * i) * 16];
-                }
+                for (int i = 0; i < NT; ++i) bv[set][i] = *reinterpret_cast<const f32x4*>(wp + i * 16 * LWS_WAVES * p.S4 + 4 * g);
             };
             auto fma = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][u], bv[set][u][i], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][u], bv[set][i][u], acc[i], 0, 0, 0);
             };
-            if (ngroups > 0) fetch(0, 0);
+            fetch(0, 0);
             int g = 0;
             for (; g + 2 <= ngroups; g += 2) {
                 fetch(g + 1, 1);
@@ -359,12 +365,6 @@ __global__ __launch_bounds__(LWS_THREADS) void lin_ws_k(LinArgs a, LinWsPlan p) 
                 fma(1);
             }
             if (g < ngroups) fma(0);
-            for (int s = ngroups * U; s < ksteps; ++s) {
-                const float a1 = ap[4 * s];
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wp[4 * s * p.NS + (wid + LWS_WAVES * i) * 16], acc[i], 0, 0, 0);
-            }
         };
         if (nmy == 2) kloop(std::integral_constant<int, 2>{});
         else if (nmy == 1) kloop(std::integral_constant<int, 1>{});

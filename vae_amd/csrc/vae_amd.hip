@@ -1667,16 +1667,17 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
     if (!g_bf16 && vec && a.B >= ws_min_b) {
         LinWsPlan p;
         const int Kt = a.K * a.nseg;
-        p.XS = Kt;
-        if (((p.XS >> 2) & 1) == 0) p.XS += 4;
-        const int budget = 40960 - 64 - LWS_RT * p.XS;  // floats of the 160 KiB
+        p.S4 = (((Kt >> 2) + 3) & ~3);         // k-steps rounded up to whole groups of four ...
+        if (((p.S4 >> 2) & 1) == 0) p.S4 += 4;  // ... and 4 * odd: 16-byte operand reads without bank conflicts
+        p.PX = (LWS_RT * p.S4 + 63) & ~63;
+        const int budget = 40960 - 64 - 4 * p.PX;  // floats of the 160 KiB
         const int Nmax = a.W2 != nullptr && a.N2 > a.N ? a.N2 : a.N;
         bool fits = LWS_RT * (Kt >> 2) <= LWS_THREADS * LWS_NJ;
-        p.NC = p.NS = 0;
+        p.NC = p.PW = 0;
         for (int g = 1; fits && g <= 16; ++g) {
-            int nc = ((Nmax + g - 1) / g + 15) & ~15, ns = nc;
-            while ((ns & 63) != 16 && (ns & 63) != 48) ns += 16;
-            if ((int64_t)ns * Kt <= budget && nc <= 16 * LWS_WAVES * LWS_MAXNT) { p.NC = nc; p.NS = ns; break; }
+            const int nc = ((Nmax + g - 1) / g + 15) & ~15;
+            const int pw = (nc * p.S4 + 63) & ~63;
+            if (4 * pw <= budget && nc <= 16 * LWS_WAVES * LWS_MAXNT) { p.NC = nc; p.PW = pw; break; }
         }
         if (fits && p.NC > 0) {
             int rc = lin_ws_grant_lds();
@@ -1687,7 +1688,7 @@ static int launch_lin(const Ctx& c, LinArgs a, const char* what) {
             int gx = 256 / (p.ng1 + p.ng2);  // one workgroup per CU: its weights fill the LDS
             if (gx < 1) gx = 1;
             if (gx > rtiles) gx = rtiles;
-            const size_t wbytes = ((size_t)Kt * p.NS + (size_t)LWS_RT * p.XS) * sizeof(float);
+            const size_t wbytes = (size_t)4 * (p.PW + p.PX) * sizeof(float);
             hipLaunchKernelGGL(lin_ws_k, dim3(gx, p.ng1 + p.ng2), dim3(LWS_THREADS), wbytes, c.s, a, p);
             VAE_TNAME("lin_ws_k");
             VAE_TBYTES(4.0 * ((double)a.B * ((double)a.K * a.nseg * (a.A2 != nullptr ? 2 : 1) + a.N + a.N2) + (double)a.K * a.nseg * (a.N + a.N2)));
