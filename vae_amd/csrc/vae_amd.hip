@@ -1740,8 +1740,13 @@ static LinWgPlan lin_wgrad_plan(int B, int N, int K) {
     static const int target = [] { const char* e = getenv("VAE_LINWG_TARGET"); return (e != nullptr && atoi(e) > 0) ? atoi(e) : 512; }();
     int gx = (target + tiles - 1) / tiles;
     // (shapes the whole-layer kernel takes: one workgroup per slice, so the slices are what fills the GPU: one 64-row
-    // chunk each up to 128 of them.  The tile kernel runs on the same slices when it has to, e.g. in bf16 mode)
-    if (lin_wgrad2_enabled(B) && lin_wgrad2_shape_ok(N, K)) gx = 128;
+    // chunk each up to 64 of them (128 from B = 32,768).  The tile kernel runs on the same slices when it has to, e.g. in bf16 mode)
+    if (lin_wgrad2_enabled(B) && lin_wgrad2_shape_ok(N, K)) {
+        // (measured: 64 / 128 slices give 0.7236 / 0.7343 ms per step at B = 8192, 1.2015 / 1.2062 at 16,384 - fewer rows
+        // for the finalize launch - and 4.07 / 4.03 at 65,536, where the kernel itself takes 296 / 254 us)
+        const char* e = getenv("VAE_LINWG2_SLICES");
+        gx = (e != nullptr && atoi(e) > 0) ? atoi(e) : (nch >= 512 ? 128 : 64);
+    }
     if (gx > nch) gx = nch;
     p.chunks_per_block = (nch + gx - 1) / gx;
     p.gx = (nch + p.chunks_per_block - 1) / p.chunks_per_block;
