@@ -101,6 +101,31 @@ def test_program_layout_is_consistent():
                 assert (r & ((1 << 56) - 1)) < sizes[r >> 56]
 
 
+def test_forward_kernel_routing_of_the_mnist_layers():
+    """vae_conv_forward_variant is a host-only query (no launch): the kernel family each MNIST conv layer runs on,
+    as DESIGN.md's kernel table states it -- 300 thin.h streaming, 400 mid_conv_k, 200 MFMA gather tiles,
+    500 scat_convT_k.  A routing change that silently sends a layer back to the chunked gather shows up here."""
+    import ctypes
+    from vae_amd import _lib as L
+    from vae_amd.program import ProgramBuilder
+    m = _build("mnist_lat15")
+    m._param_off, off = {}, 0
+    for _, p in m.named_parameters():
+        m._param_off[id(p)] = off
+        off += (p.numel() + 3) // 4 * 4
+    m._state_off, soff = {}, 0
+    for b_ in m._float_buffers():
+        m._state_off[id(b_)] = soff
+        soff += (b_.numel() + 3) // 4 * 4
+    for B in (32, 4096):
+        b = ProgramBuilder(B, m._param_off, m._state_off)
+        m.emit_program(b, True)
+        got = [(op.kind, L.lib().vae_conv_forward_variant(ctypes.byref(op), B))
+               for op in b.build().ops if op.kind in (L.OP_CONV, L.OP_CONVT)]
+        assert got == [(L.OP_CONV, 300), (L.OP_CONV, 400), (L.OP_CONV, 200),
+                       (L.OP_CONVT, 500), (L.OP_CONVT, 500), (L.OP_CONVT, 300)], (B, got)
+
+
 def test_gradient_buckets_split_at_the_reparameterisation():
     """DataParallelTrainStep's two gradient buckets (vae_run_backward_range): decoder + loss ops first, then the
     encoder; the flat-buffer ranges partition the parameters at the first decoder parameter."""
