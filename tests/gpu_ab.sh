@@ -1,11 +1,16 @@
 #!/bin/bash
-# usage: gpu_ab.sh VAR "v1 v2 ..." [bench args]: ms/step of the default bench under each value of the environment variable
-VAR=$1; VALS=$2; shift 2
-for v in $VALS; do
-  for rep in 1 2; do
-    env $VAR=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-strong-ref --steps 300 --warmup 30 --roofline-iters 3 "$@" 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); r=d['roofline']
-print('$VAR=$v', 'ms/step %.4f' % d['ms_per_step'], 'launches', r['step_launches'], 'sum_us %.1f' % r['step_sum_of_launches_us'])" || exit 1
+# A/B of two builds of the library on ONE box (step times differ by 1-2 % from box to box): alternates the builds.
+# usage: tests/gpu_ab.sh <old.so> [rounds]   (the new build is the in-tree library)
+OLD=$1; R=${2:-3}
+for i in $(seq $R); do
+  for w in old new; do
+    if [ $w = old ]; then export VAE_AMD_LIB=$OLD; else unset VAE_AMD_LIB; fi
+    timeout -k 10 120 python bench.py --no-cpu-baseline --no-strong-ref --roofline-iters 5 > gpurun_out/ab_$w.json || exit 1
+    python - $w <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
+fam = {f["kernel"]: f["us_per_step"] for f in d["roofline"]["families"]}
+print(sys.argv[1], round(d["ms_per_step"], 4), "fc", [fam.get(k) for k in ("fc_chain_k<true>", "fc_chain_k<false>")], flush=True)
+PY
   done
 done

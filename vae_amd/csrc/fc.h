@@ -106,52 +106,75 @@ __device__ __forceinline__ uint64_t fc_u64(const void* p) {
 __device__ __forceinline__ fc_gcp fc_u(const float* p) { return (fc_gcp)fc_u64(p); }
 __device__ __forceinline__ fc_gp fc_u(float* p) { return (fc_gp)fc_u64(p); }
 
+// Loads and stores of fc_chain_k address memory as (wave-uniform base pointer) + (32-bit byte offset of the lane): the
+// instruction takes the base from SGPRs and ONE VGPR, and the offset costs one or two 32-bit VALU operations instead
+// of a 64-bit multiply-add per access.  (Measured: four waves share a SIMD, and the address arithmetic of the weight
+// loads was the largest part of the kernel's VALU instructions.)  fc_finish checks the ranges: every byte offset below
+// 2^31, rows and leading dimensions (in bytes) below 2^24 for the 24-bit multiplies.
+typedef const __attribute__((address_space(1))) char* fc_gcb;
+typedef __attribute__((address_space(1))) char* fc_gb;
+__device__ __forceinline__ float fc_ld(fc_gcp base, uint32_t boff) {
+    return *reinterpret_cast<fc_gcp>(reinterpret_cast<fc_gcb>(base) + boff);
+}
+__device__ __forceinline__ f32x4 fc_ld4(fc_gcp base, uint32_t boff) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(reinterpret_cast<fc_gcb>(base) + boff);
+}
+__device__ __forceinline__ void fc_st(fc_gp base, uint32_t boff, float v) {
+    *reinterpret_cast<fc_gp>(reinterpret_cast<fc_gb>(base) + boff) = v;
+}
+
 // The weights of one chunk (k-steps s0 .. s0 + FC_U of segment seg of the tile `item`) and the tile's bias and act'(Y)
-// inputs.  Every load is unconditional, with clamped indices: the s_waitcnt in front of the MFMAs can then count the
+// inputs.  Every load is unconditional, with clamped offsets: the s_waitcnt in front of the MFMAs can then count the
 // loads of the NEXT chunk that may stay in flight (a load under a branch makes that count unknown and the wait a
-// vmcnt(0), which serialises the prefetch), and nothing has to be zeroed: a clamped k meets zero padding on the A
-// side, a clamped column is not stored.  VEC: some GEMM stage of the run has the reduction index contiguous in memory
-// (wsk == 1, K % 4 == 0, aligned rows: st.vec) and takes one dwordx4 per k-step; else four dwords per k-step.  Offsets are 32-bit from the
-// (wave-uniform) weight pointer, so the loads take an SGPR base and one VGPR each.
+// vmcnt(0), which serialises the prefetch -- which is also why an absent bias / act'(Y) is a load of offset 0 through
+// a MASK: the select it used to be was compiled into a branch whose short side waited for vmcnt(0)), and nothing has
+// to be zeroed: a clamped k meets zero padding on the A side, a clamped column is not stored.  VEC: some GEMM stage of
+// the run has the reduction index contiguous in memory (wsk == 1, K % 4 == 0, aligned rows: st.vec) and takes one
+// dwordx4 per k-step; else four dwords per k-step.
 template <bool VEC>
 __device__ __forceinline__ void fc_fetch(const FcChain& ch, int item, int seg, int s0, float4 (&b)[FC_U], float& bias,
                                          float (&my)[4], int m0, int li, int lk) {
     const FcStage& st = ch.st[(item >> 8) & 15];
     const int K = fc_u(st.K), N = fc_u(st.N);
-    const uint32_t wsk = (uint32_t)fc_u((int)st.wsk), wsn = (uint32_t)fc_u((int)st.wsn);
+    const uint32_t wsk4 = 4u * (uint32_t)fc_u((int)st.wsk), wsn4 = 4u * (uint32_t)fc_u((int)st.wsn);
     const fc_gcp W = fc_u(seg ? st.W2 : st.W);
     const fc_gcp bp = fc_u(st.bias);  // (never null: the host points absent ones at the weights, has_bias / has_mul = 0)
     const fc_gcp yp = fc_u(st.mulY);
-    const int ldmy = fc_u(st.ldmy), B = fc_u(ch.B), has_bias = fc_u(st.has_bias), has_mul = fc_u(st.has_mul);
-    const int n = min((item & 255) * 16 + li, N - 1);
-    const uint32_t woff = (uint32_t)n * wsn;
+    const uint32_t ldmy4 = 4u * (uint32_t)fc_u(st.ldmy);
+    const int B = fc_u(ch.B);
+    const uint32_t bias_mask = (uint32_t)-fc_u(st.has_bias), mul_mask = (uint32_t)-fc_u(st.has_mul);
+    const uint32_t n = (uint32_t)min((item & 255) * 16 + li, N - 1);
+    const uint32_t woff = __umul24(n, wsn4);
 #if defined(FC_DIAG) && FC_DIAG == 1  // diagnostic build: no weight traffic
     for (int u = 0; u < FC_U; ++u) b[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     if (false)
 #endif
-    if (VEC && fc_u(st.vec)) {  // (VEC kernel, stage without it: the dword path below; the waits then count the nine
+    if (VEC && fc_u(st.vec)) {  // (VEC kernel, stage without it: the dword path below; the waits then count the
                                 // loads of this path, which holds that stage's prefetch back, not the others')
+        const uint32_t k0 = woff + 16u * (uint32_t)lk + 64u * (uint32_t)s0, kmax = woff + 4u * (uint32_t)(K - 4);
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int kk = min(16 * (s0 + u) + 4 * lk, K - 4);
-            const f32x4 t = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + (woff + (uint32_t)kk));
+            const f32x4 t = fc_ld4(W, min(k0 + 64u * u, kmax));
             b[u] = make_float4(t[0], t[1], t[2], t[3]);
         }
     } else {
+        const uint32_t k0 = woff + __umul24(4u * (uint32_t)lk, wsk4), kmax = woff + (uint32_t)(K - 1) * wsk4;
+        const uint32_t sk = 16u * (uint32_t)s0 * wsk4;  // (uniform: the scalar unit's arithmetic)
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int kk = 16 * (s0 + u) + 4 * lk;
-            b[u].x = W[woff + (uint32_t)min(kk, K - 1) * wsk];
-            b[u].y = W[woff + (uint32_t)min(kk + 1, K - 1) * wsk];
-            b[u].z = W[woff + (uint32_t)min(kk + 2, K - 1) * wsk];
-            b[u].w = W[woff + (uint32_t)min(kk + 3, K - 1) * wsk];
+            const uint32_t su = sk + 16u * u * wsk4;
+            b[u].x = fc_ld(W, min(k0 + su, kmax));
+            b[u].y = fc_ld(W, min(k0 + (su + wsk4), kmax));
+            b[u].z = fc_ld(W, min(k0 + (su + 2u * wsk4), kmax));
+            b[u].w = fc_ld(W, min(k0 + (su + 3u * wsk4), kmax));
         }
     }
-    bias = bp[has_bias ? n : 0];
+    bias = fc_ld(bp, (4u * n) & bias_mask);
+    const uint32_t n4m = (4u * n) & mul_mask, ldm = ldmy4 & mul_mask;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int m = min(m0 + 4 * lk + r, B - 1);
-        my[r] = yp[has_mul ? (int64_t)m * ldmy + n : 0];
+        const uint32_t m = (uint32_t)min(m0 + 4 * lk + r, B - 1);
+        my[r] = fc_ld(yp, __umul24(m, ldm) + n4m);
     }
 }
 
@@ -348,7 +371,8 @@ __global__ __launch_bounds__(FC_THREADS) void fc_chain_k(FcChain ch) {
             }
         }
         if (ni != ci) {  // the tile is complete.  D: column li, rows 4 lk + r
-            const int N = fc_u(st.N), ldo = fc_u(st.ldo), act = fc_u(st.act), accumulate = fc_u(st.accumulate);
+            const int N = fc_u(st.N), act = fc_u(st.act), accumulate = fc_u(st.accumulate);
+            const uint32_t ldo4 = 4u * (uint32_t)fc_u(st.ldo);
             const int out_off = fc_u(st.out_off), out_stride = fc_u(st.out_stride), mul_act = fc_u(st.mul_act);
             const float slope = fc_u(st.slope), mul_slope = fc_u(st.mul_slope);
             const fc_gp out = fc_u(st.out);
@@ -362,9 +386,9 @@ __global__ __launch_bounds__(FC_THREADS) void fc_chain_k(FcChain ch) {
                 const bool ok = n_ok && m < B;
                 float v = act_apply(acc0[r] + acc1[r] + bv, act, slope);
                 if (ok) {
-                    const fc_gp gp = out + (int64_t)m * ldo + n;
-                    if (accumulate) v += *gp;
-                    *gp = v;
+                    const uint32_t go = __umul24((uint32_t)m, ldo4) + 4u * (uint32_t)n;
+                    if (accumulate) v += fc_ld(out, go);
+                    fc_st(out, go, v);
                 }
                 if (out_off >= 0) {
                     float l = ok ? v : 0.f;

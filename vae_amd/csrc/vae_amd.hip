@@ -2082,6 +2082,19 @@ static int fc_finish(FcBuild& fb, int B) {
     for (int k = 0; k < ch.n; ++k) nlev = ch.st[k].level + 1 > nlev ? ch.st[k].level + 1 : nlev;
     std::stable_sort(ch.st, ch.st + ch.n, [](const FcStage& a, const FcStage& b) { return a.level < b.level; });
     ch.B = B;
+    // fc_chain_k addresses weights, outputs and act'(Y) rows as base + 32-bit byte offset, with 24-bit multiplies
+    // (fc.h: fc_ld): anything outside those ranges goes to the per-op kernels
+    for (int k = 0; k < ch.n; ++k) {
+        const FcStage& s = ch.st[k];
+        if (s.kind != FC_GEMM) continue;
+        const int64_t lim = (int64_t)1 << 31, u24 = (int64_t)1 << 24;
+        if (B >= u24 || s.N >= u24 || 4 * s.wsk >= u24 || 4 * s.wsn >= u24 || 4 * (int64_t)s.ldo >= u24 ||
+            4 * (int64_t)s.ldmy >= u24)
+            return 0;
+        if (4 * ((s.N - 1) * s.wsn + (s.K - 1) * s.wsk + 4) >= lim || 4 * ((int64_t)(B - 1) * s.ldo + s.N) >= lim ||
+            (s.mulY != nullptr && 4 * ((int64_t)(B - 1) * s.ldmy + s.N) >= lim))
+            return 0;
+    }
     for (int k = 0; k < ch.n; ++k) {  // fc_fetch loads the bias and act'(Y) unconditionally: absent ones read a weight
         FcStage& s = ch.st[k];
         if (s.kind != FC_GEMM) continue;
