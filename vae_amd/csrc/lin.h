@@ -422,15 +422,11 @@ struct LinWgMulti {
     int n;
 };
 
-template <bool BF>
-__global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
-    __shared__ __attribute__((aligned(16))) float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+64)
-    __shared__ __attribute__((aligned(16))) float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
-    int layer = 0;
-#pragma unroll
-    for (int i = 1; i < LIN_WG_MAX_LAYERS; ++i)
-        if (i < m.n && (int)blockIdx.x >= m.l[i].first_block) layer = i;
-    const LinWgArgs& a = m.l[layer];
+// One workgroup's tile.  VEC (the layer's a.vec) is a template argument, not a run-time branch inside the staging code:
+// with both shapes of the prefetch registers in one body the compiler left three of them in scratch memory, and every
+// access to those drained the next chunk's loads (scratch counts in vmcnt).
+template <bool BF, bool VEC>
+__device__ __forceinline__ void lw_tile(const LinWgArgs& a, float* Ys, float* Xs) {
     const int bid = blockIdx.x - a.first_block;
     const int bx = bid % a.gx, by = (bid / a.gx) % a.gy, bz = bid / (a.gx * a.gy);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -447,10 +443,12 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     const int c_end = min(c_first + a.chunks_per_block, (a.B + LW_BB - 1) / LW_BB);
     const bool has_act = a.act != VAE_ACT_NONE;
     float vy[16], vyy[16], vx[16];
-    const bool vec = a.vec != 0;
-    auto load_chunk = [&](int ch) {  // 64 rows x 64 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vyy[j] = 0.f;
+    constexpr bool vec = VEC;
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {  // 64 rows x 64 dY (and Y) columns, 64 rows x 64 X columns; zero past the edges
         const int b0 = ch * LW_BB;
-        if (vec) {
+        if constexpr (vec) {
             // four float4 per tensor and thread, every load unconditional with a clamped address (a load under a branch
             // is waited for on the spot); what lies past an edge is zeroed when it goes to LDS
 #pragma unroll
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
     if (c_first < c_end) load_chunk(c_first);
     for (int ch = c_first; ch < c_end; ++ch) {
         __syncthreads();
-        if (vec) {
+        if constexpr (vec) {
             const int b0 = ch * LW_BB;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -566,6 +564,19 @@ __global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
             if (k + 48 < a.K) prow[(int64_t)n * a.K + k + 48] = acc3[r];
         }
     }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(LIN_THREADS) void lin_wgrad_k(LinWgMulti m) {
+    __shared__ __attribute__((aligned(16))) float Ys[LW_BB * LW_YS];  // dY' chunk: [b][n0..n0+64)
+    __shared__ __attribute__((aligned(16))) float Xs[LW_BB * LW_XS];  // X chunk:   [b][k0..k0+64)
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < LIN_WG_MAX_LAYERS; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.l[i].first_block) layer = i;
+    const LinWgArgs& a = m.l[layer];
+    if (a.vec != 0) lw_tile<BF, true>(a, Ys, Xs);
+    else lw_tile<BF, false>(a, Ys, Xs);
 }
 
 // ---- weight / bias gradient, whole layer per workgroup (round 3) ----------------------------------------------------
