@@ -48,9 +48,12 @@ def parse_args():
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--rank-timeout", type=int, default=900,
                     help="--gpus N > 1 started by this script: seconds after which the ranks are killed (0: never)")
+    ap.add_argument("--dp-overlap", action="store_true",
+                    help="N > 1 on RCCL: two communicators, the decoder's gradient bucket all-reduced on a side stream while "
+                         "the encoder's backward runs.  Off by default: no box with more than one GPU was in reach of the "
+                         "build, so the default is the arrangement with no two collectives in flight together")
     ap.add_argument("--dp-single-comm", action="store_true",
-                    help="N > 1 on RCCL: one communicator and one stream for every collective (no overlap; the fallback "
-                         "should two communicators in flight stall)")
+                    help="(the default since round 3; kept so that older command lines still parse)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="compute dtype of the matrix kernels: f32 (the headline) or bf16 operands with fp32 accumulate "
                          "and fp32 storage (vae_set_compute_dtype; BASELINE configs[1] 'fp32 then bf16')")
@@ -289,7 +292,8 @@ def main():
 
         def _expired():
             print(f"bench.py rank {rank}: not finished within --rank-timeout {args.rank_timeout}s (a collective that "
-                  "never completed?): exiting; try --dp-single-comm or VAE_BENCH_BACKEND=gloo", file=sys.stderr, flush=True)
+                  "never completed?): exiting; try VAE_BENCH_BACKEND=gloo (collectives staged through the host)",
+                  file=sys.stderr, flush=True)
             os._exit(3)
         watchdog = threading.Timer(args.rank_timeout, _expired)
         watchdog.daemon = True
@@ -334,7 +338,7 @@ def main():
     else:
         from vae_amd.parallel import DataParallelTrainStep
         stepper = DataParallelTrainStep(model, opt, B, dev, use_graph=args.dp_graph and backend == "nccl",
-                                        single_comm=True if args.dp_single_comm else None)
+                                        single_comm=not args.dp_overlap)
     stepper.step(x)
 
     def barrier():
@@ -380,8 +384,13 @@ def main():
         if world == 1:
             par = "single GPU, whole step as one hipGraph" if not args.no_graph else "single GPU, eager launches"
         else:
-            coll = (("RCCL enqueued by the library on the step's streams, no host callback" +
-                     (", whole step captured as one hipGraph" if stepper.use_graph else ", eager launches"))
+            native = getattr(stepper, "native", False)
+            how = ("RCCL through torch.distributed from the SyncBN callback" if not native else
+                   "RCCL enqueued by the library, no host callback, " +
+                   ("one communicator on the compute stream, the gradient in one all-reduce behind the backward pass"
+                    if getattr(stepper, "single_comm", False) else
+                   "two communicators: the decoder's gradient bucket reduced on a side stream beside the encoder's backward"))
+            coll = ((how + (", whole step captured as one hipGraph" if stepper.use_graph else ", eager launches"))
                     if backend == "nccl" else f"{backend} (rehearsal: ranks share {ngpu} GPU(s), collectives staged through the host)")
             par = f"dp{world}: batch shards, SyncBN all-gather per BatchNorm, grad all-reduce SUM ({coll})"
         line = {

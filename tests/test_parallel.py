@@ -100,11 +100,13 @@ def test_collective_rccl_single_rank():
 
 
 @pytest.mark.gpu
-def test_native_rccl_step_single_rank():
+@pytest.mark.parametrize("single_comm", [False, True])
+def test_native_rccl_step_single_rank(single_comm):
     """The library's own RCCL path (vae_dp_*: SyncBN all-gather + gradient all-reduce enqueued from C on the caller's
     streams) at world 1, the most one GPU allows (RCCL refuses two ranks on one device): the exchanges run through
     the C-ABI, the data-parallel step makes no callback into Python, equals the single-GPU fused step bit for bit
-    (an all-reduce over one rank is the identity), and can be captured into one hipGraph, collectives included."""
+    (an all-reduce over one rank is the identity), and can be captured into one hipGraph, collectives included.
+    single_comm: VAE_DP_SINGLE_COMM=1 -- one communicator, every collective on the compute stream, one gradient bucket."""
     code = (
         "import os, sys, copy, ctypes, torch, torch.distributed as dist\n"
         f"sys.path.insert(0, {ROOT!r})\n"
@@ -140,6 +142,8 @@ def test_native_rccl_step_single_rank():
         "for graph in (False, True):\n"
         "    st, l1, p1 = run(lambda m, o: DataParallelTrainStep(m, o, B, 'cuda', use_graph=graph))\n"
         "    assert st.native and st.hook_calls == 0\n"
+        f"    assert st.single_comm == {single_comm!r} and (st.comm_stream is None) == {single_comm!r}\n"
+        f"    assert L.lib().vae_dp_single_comm() == {int(single_comm)}\n"
         "    assert (st.graph is not None) == graph\n"
         "    assert l1 == l0, (graph, l0, l1)\n"
         "    assert torch.equal(p0, p1), (graph, float((p0 - p1).abs().max()))\n"
@@ -147,6 +151,7 @@ def test_native_rccl_step_single_rank():
         "assert L.lib().vae_dp_world() == 0\n"
         "dist.destroy_process_group()\n"
         "print('NATIVE-OK')\n")
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               VAE_DP_SINGLE_COMM="1" if single_comm else "0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "NATIVE-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

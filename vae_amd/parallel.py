@@ -171,7 +171,8 @@ class DataParallelTrainStep(FusedTrainStep):
         CPU tests, ranks sharing one GPU).  use_graph (native only): the whole step, collectives included, is captured
         into one hipGraph and replayed.  single_comm (native only; None: environment variable VAE_DP_SINGLE_COMM):
         one RCCL communicator and ONE stream for the SyncBN gathers and the gradient all-reduces -- no two collectives
-        in flight together, no overlap; the fallback should the two-communicator overlap stall on a system."""
+        in flight together, no overlap, the gradient in one all-reduce behind the backward pass; what bench.py runs by
+        default at N > 1, and the fallback should the two-communicator overlap stall on a system."""
         # The 1-D families keep their whole-model path (one launch per BatchNorm-delimited phase): between two phases
         # every rank folds its workgroups' statistics rows into one row, the rows are all-gathered through the same
         # hook, and the next phase's prologue merges `world` rows (seq1d_host.h: sq_exchange).  allow_seq1d=False:
@@ -243,6 +244,10 @@ class DataParallelTrainStep(FusedTrainStep):
         try:
             self.prog.forward(self.work, self.flat, self.sflat, ext, True, stream=stream)
             buckets = self.buckets if self.buckets is not None else [(0, self.prog.n_ops, 0, None)]
+            if self.comm_stream is None:
+                # one communicator, one stream: nothing can overlap, so the whole gradient goes in ONE all-reduce behind
+                # the backward pass (two buckets in stream order would expose two collective latencies instead of one)
+                buckets = [(0, self.prog.n_ops, 0, None)]
             done = []
             for i, (begin, end, lo, hi) in enumerate(buckets):
                 self.prog.backward_range(self.work, self.flat, self.grads, self.sflat, ext, begin, end, i == 0,
