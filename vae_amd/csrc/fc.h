@@ -145,6 +145,15 @@ __device__ __forceinline__ void fc_fetch(const FcChain& ch, int item, int seg, i
     const uint32_t bias_mask = (uint32_t)-fc_u(st.has_bias), mul_mask = (uint32_t)-fc_u(st.has_mul);
     const uint32_t n = (uint32_t)min((item & 255) * 16 + li, N - 1);
     const uint32_t woff = __umul24(n, wsn4);
+    // (the five small loads first: behind the weight loads, the compiler protected their address temporaries with a
+    // wait that also drained the weights just requested)
+    bias = fc_ld(bp, (4u * n) & bias_mask);
+    const uint32_t n4m = (4u * n) & mul_mask, ldm = ldmy4 & mul_mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t m = (uint32_t)min(m0 + 4 * lk + r, B - 1);
+        my[r] = fc_ld(yp, __umul24(m, ldm) + n4m);
+    }
 #if defined(FC_DIAG) && FC_DIAG == 1  // diagnostic build: no weight traffic
     for (int u = 0; u < FC_U; ++u) b[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     if (false)
@@ -168,13 +177,6 @@ __device__ __forceinline__ void fc_fetch(const FcChain& ch, int item, int seg, i
             b[u].z = fc_ld(W, min(k0 + (su + 2u * wsk4), kmax));
             b[u].w = fc_ld(W, min(k0 + (su + 3u * wsk4), kmax));
         }
-    }
-    bias = fc_ld(bp, (4u * n) & bias_mask);
-    const uint32_t n4m = (4u * n) & mul_mask, ldm = ldmy4 & mul_mask;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t m = (uint32_t)min(m0 + 4 * lk + r, B - 1);
-        my[r] = fc_ld(yp, __umul24(m, ldm) + n4m);
     }
 }
 
