@@ -66,8 +66,12 @@ enum {
     VAE_F_FUSED = 64,      /* CONV/CONVT: LDS-staged MFMA implicit-GEMM kernels; BN: "virtual" (its output is
                               never materialised: the producer's epilogue takes the statistics, the consumer
                               normalises on load, and the backward pass is folded the same way) */
-    VAE_F_LOSS_IN_BWD = 128, /* ELBO: forward leaves the per-workgroup partials; the fixed-order sum into out[0..3]
-                              is done by the op's backward launch (a train step always runs it: one launch less).
+    VAE_F_LOSS_IN_BWD = 128, /* ELBO: the caller promises that the op's backward runs behind every forward (a train
+                              step).  Target laid out like x_rec (d[2] == 1, d[1] == d[0]): forward launches nothing,
+                              backward computes the loss terms and the gradient in one pass (elbo_fused_k) and the
+                              fixed-order sum into out[0..3] rides on the weight-gradient reduction that ends the
+                              backward call.  Otherwise forward leaves the per-workgroup partials and the op's backward
+                              launch adds them.  Either way out[0..3] is valid after the backward call, not before.
                               No counterpart in the reference (train.py:39-48 computes the loss eagerly). */
     VAE_F_BN_ACC = 256,    /* BN (VAE_F_FUSED): the save block r[6] is followed by VAE_BN_ACC_FLOATS(C) floats of
                               fixed-point accumulators (the producers' per-channel sums, added with 64-bit integer

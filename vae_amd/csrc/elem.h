@@ -182,6 +182,60 @@ __global__ __launch_bounds__(256) void elbo_bwd_k(const float* __restrict__ xr, 
         }
 }
 
+// The ELBO of a train step in ONE launch (VAE_F_LOSS_IN_BWD, target laid out like x_rec): the loss terms and
+// d(loss)/d(x_rec) come from the same pass over x_rec and the target (the two-launch form reads both twice: 38 MB
+// instead of 26 MB per step at B = 4096, and a graph node more).  Grid and loop are those of elbo_fwd_k, so every
+// workgroup's partial pair -- and with it the loss -- equals the two-launch form's bit for bit.  The fixed-order sum of
+// the pairs is left to a LATER launch of the backward pass (wgrad_finalize_k's workgroup 0, else elbo_finalize_k): a
+// last-workgroup-done ticket inside this kernel was measured at 38 us instead of 8 -- the device-scope release fence
+// in front of the ticket writes the XCD's L2 back, and this kernel has just filled it with 12.8 MB of gradient.  Also
+// what elbo_bwd_k does as the first kernel of a backward pass: it clears the flat gradient buffer and the BatchNorm
+// accumulators.  The KL gradients are the REPARAM op's (VAE_F_KL_GRAD).
+__global__ __launch_bounds__(256) void elbo_fused_k(const float* __restrict__ xr, const float* __restrict__ tg,
+                                                    const float* __restrict__ mu, const float* __restrict__ lv,
+                                                    const float* __restrict__ gscale, float* __restrict__ dxr,
+                                                    float* __restrict__ partials, int64_t B, int nps, int latent,
+                                                    int bce, float* __restrict__ zero_buf, int64_t zero_n,
+                                                    ZeroRanges zr) {
+    __shared__ float sm[4];
+    const float gs = gscale != nullptr ? gscale[0] : 1.f;
+    const int64_t nrec = B * nps, nkl = B * latent;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i < zero_n; i += stride) zero_buf[i] = 0.f;
+    for (int q = 0; q < zr.cnt; ++q)
+        for (int64_t i = i0; i < zr.n[q]; i += stride) zr.p[q][i] = 0.f;
+    float rec = 0.f, rec2 = 0.f, kl = 0.f;
+    auto grad = [&](float p, float t) {
+        return (bce ? (p - t) / fmaxf((1.f - p) * p, 1e-12f) : 2.f * (p - t)) * gs;  // (elbo_bwd_k)
+    };
+    int64_t i = i0;
+    for (; i + stride < nrec; i += 2 * stride) {
+        const float p0 = xr[i], t0 = tg[i], p1 = xr[i + stride], t1 = tg[i + stride];
+        if (bce) { rec += bce_term(p0, t0); rec2 += bce_term(p1, t1); }
+        else { rec = fmaf(p0 - t0, p0 - t0, rec); rec2 = fmaf(p1 - t1, p1 - t1, rec2); }
+        dxr[i] = grad(p0, t0);
+        dxr[i + stride] = grad(p1, t1);
+    }
+    if (i < nrec) {
+        const float p = xr[i], t = tg[i];
+        if (bce) rec += bce_term(p, t);
+        else rec = fmaf(p - t, p - t, rec);
+        dxr[i] = grad(p, t);
+    }
+    rec += rec2;
+    for (int64_t j = i0; j < nkl; j += stride) {
+        const float m = mu[j], l = lv[j];
+        kl += 1.f + l - m * m - expf(l);
+    }
+    const float r = block_sum_256(rec, sm);
+    const float k = block_sum_256(kl, sm);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = r;
+        partials[2 * blockIdx.x + 1] = -0.5f * k;
+    }
+}
+
 // ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {

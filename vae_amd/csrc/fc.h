@@ -283,7 +283,9 @@ __global__ __launch_bounds__(FC_THREADS) void fc_chain_k(FcChain ch) {
             ly[q] = yq[(int64_t)m * ldy + c];
         }
     }
-    for (int e = tid; e < fc_u(ch.lds_floats); e += FC_THREADS) fc_lds[e] = 0.f;  // the padding columns stay zero
+    // the padding columns stay zero (16 bytes per lane and store: every buffer is 16 rows of a multiple of 4 floats)
+    for (int e = 4 * tid; e < fc_u(ch.lds_floats); e += 4 * FC_THREADS)
+        *reinterpret_cast<float4*>(fc_lds + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ci < nit) fc_fetch<VEC>(ch, item_at(ci), 0, 0, P, pb, pm, m0, li, lk);
     lds_barrier();
     IG_T();

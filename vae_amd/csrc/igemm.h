@@ -994,9 +994,30 @@ struct WgFinLayer {
 struct WgFinMulti {
     WgFinLayer l[WG_FIN_MAX_LAYERS];
     int n;
+    // elbo_fused_k's per-workgroup {recon, kld} pairs, summed by ONE EXTRA workgroup (the grid's last) in
+    // elbo_finalize_k's order into out[0..3]; nullptr: none pending
+    const float* loss_part;
+    float* loss_out;
+    int loss_blocks, loss_accumulate;
 };
 __global__ __launch_bounds__(256) void wgrad_finalize_k(WgFinMulti m) {
     __shared__ float red[16][17];
+    if (m.loss_part != nullptr && blockIdx.x == gridDim.x - 1) {
+        float r = 0.f, k = 0.f;
+        for (int i = threadIdx.x; i < m.loss_blocks; i += blockDim.x) {
+            r += m.loss_part[2 * i];
+            k += m.loss_part[2 * i + 1];
+        }
+        r = block_sum_256(r, &red[0][0]);
+        k = block_sum_256(k, &red[0][0]);
+        if (threadIdx.x == 0) {
+            m.loss_out[0] = r + k;
+            m.loss_out[1] = r;
+            m.loss_out[2] = k;
+            if (m.loss_accumulate) m.loss_out[3] += r + k;
+        }
+        return;
+    }
     int layer = 0;
 #pragma unroll
     for (int i = 1; i < WG_FIN_MAX_LAYERS; ++i)

@@ -586,7 +586,14 @@ static int64_t wgrad_part_floats(const WgPlan& wp, int B) {
 static int flush_linear_wgrads(const Ctx& c);
 static int flush_wgrad_finalize(const Ctx& c) {
     WgFinMulti& m = c.wg_fin;
-    if (m.n == 0) return VAE_OK;
+    if (m.n == 0) {
+        if (m.loss_part == nullptr) return VAE_OK;
+        // a backward pass without a weight-gradient reduction: the loss sum gets a launch of its own
+        hipLaunchKernelGGL(elbo_finalize_k, dim3(1), dim3(256), 0, c.s, m.loss_part, m.loss_out, m.loss_blocks, m.loss_accumulate);
+        m.loss_part = nullptr;
+        VAE_LAUNCH_CHECK("elbo_finalize_k");
+        return VAE_OK;
+    }
     int rc = flush_linear_wgrads(c);  // the Linear layers' partial rows must exist before they are reduced
     if (rc) return rc;
     int blocks = 0;
@@ -594,7 +601,9 @@ static int flush_wgrad_finalize(const Ctx& c) {
         m.l[i].first_block = blocks;
         blocks += (m.l[i].ncols + 15) / 16;
     }
-    hipLaunchKernelGGL(wgrad_finalize_k, dim3(blocks), dim3(256), 0, c.s, m);
+    // (+1: the workgroup that sums a pending elbo_fused_k's partial pairs)
+    hipLaunchKernelGGL(wgrad_finalize_k, dim3(blocks + (m.loss_part != nullptr ? 1 : 0)), dim3(256), 0, c.s, m);
+    m.loss_part = nullptr;
     if (vae_tl_timer != nullptr) {
         double fl = 0;
         for (int i = 0; i < m.n; ++i) fl += (double)(m.l[i].nrows + 2) * m.l[i].ncols;
@@ -2316,6 +2325,14 @@ static int elbo_fwd_impl(hipStream_t s, const float* xr, const float* tg, const 
 static inline int64_t target_extent(int B, int nps, int64_t sb, int64_t se) {
     return (int64_t)(B - 1) * sb + (int64_t)(nps - 1) * se + 1;
 }
+// VAE_F_LOSS_IN_BWD promises that the op's backward runs behind every forward: with the target laid out like x_rec the
+// loss terms and the gradient then come from one pass over x_rec (elem.h: elbo_fused_k; VAE_AMD_ELBO_FUSED=0: the
+// two-launch form); the fixed-order sum of the workgroups' pairs rides on the weight-gradient reduction at the end of
+// the backward call that holds the op.
+static bool elbo_fused(const vae_op& op) {
+    static const int on = [] { const char* e = getenv("VAE_AMD_ELBO_FUSED"); return (e != nullptr && *e) ? atoi(e) != 0 : 1; }();
+    return on && (op.flags & VAE_F_LOSS_IN_BWD) && op.d[2] == 1 && op.d[1] == op.d[0];
+}
 static int elbo_forward(const Ctx& c, const vae_op& op) {
     const int nps = op.d[0], latent = op.d[3];
     if (nps < 1 || latent < 1 || op.d[1] < 0 || op.d[2] < 0) VAE_FAIL(VAE_EINVAL, "elbo: bad shape");
@@ -2327,6 +2344,7 @@ static int elbo_forward(const Ctx& c, const vae_op& op) {
     float* out = resolve(c, op.r[4], 4, "elbo.out", &ok);
     float* part = resolve(c, op.r[6], 2 * VAE_ELBO_BLOCKS, "elbo.partials", &ok);
     if (!ok) return VAE_EINVAL;
+    if (elbo_fused(op)) return VAE_OK;  // the op's backward launch computes the loss as well (elbo_fused_k)
     return elbo_fwd_impl(c.s, xr, tg, mu, lv, out, part, c.B, nps, op.d[1], op.d[2], latent,
                          (op.flags & VAE_F_BCE) ? 1 : 0, op.d[5], !(op.flags & VAE_F_LOSS_IN_BWD));
 }
@@ -2345,6 +2363,23 @@ static int elbo_backward(const Ctx& c, const vae_op& op, float* zero_buf = nullp
         fin_out = resolve(c, op.r[4], 4, "elbo.out", &ok);
     }
     if (!ok) return VAE_EINVAL;
+    if (elbo_fused(op)) {
+        const float* mu = resolve(c, op.r[2], (int64_t)c.B * latent, "elbo.mu", &ok);
+        const float* lv = resolve(c, op.r[3], (int64_t)c.B * latent, "elbo.logvar", &ok);
+        float* part = resolve(c, op.r[6], 2 * VAE_ELBO_BLOCKS, "elbo.partials", &ok);
+        float* out = resolve(c, op.r[4], 4, "elbo.out", &ok);
+        if (!ok) return VAE_EINVAL;
+        hipLaunchKernelGGL(elbo_fused_k, dim3(VAE_ELBO_BLOCKS), dim3(256), 0, c.s, xr, tg, mu, lv, gs, dxr, part,
+                           (int64_t)c.B, nps, latent, (op.flags & VAE_F_BCE) ? 1 : 0, zero_buf, zero_n,
+                           zr != nullptr ? *zr : ZeroRanges{});
+        // the sum of the pairs rides on this pass's weight-gradient reduction (flush_wgrad_finalize)
+        c.wg_fin.loss_part = part; c.wg_fin.loss_out = out; c.wg_fin.loss_blocks = VAE_ELBO_BLOCKS;
+        c.wg_fin.loss_accumulate = op.d[5];
+        VAE_TNAME("elbo_fused_k");
+        VAE_TBYTES(12.0 * (double)c.B * nps + 8.0 * (double)c.B * latent + 4.0 * (double)zero_n);
+        VAE_LAUNCH_CHECK("elbo_fused_k");
+        return VAE_OK;
+    }
     // KL gradients are folded into the REPARAM op's backward (VAE_F_KL_GRAD)
     hipLaunchKernelGGL(elbo_bwd_k, dim3(ew_grid((int64_t)c.B * nps)), dim3(256), 0, c.s, xr, tg, nullptr, nullptr, gs,
                        dxr, nullptr, nullptr, (int64_t)c.B, nps, (int64_t)op.d[1], (int64_t)op.d[2], latent,
@@ -2368,6 +2403,7 @@ static int make_ctx(Ctx* c, const vae_op* ops, int n_ops, float* const* bases, c
     c->last_blocks = 0;
     c->lin_wg.n = 0;
     c->wg_fin.n = 0;
+    c->wg_fin.loss_part = nullptr; c->wg_fin.loss_out = nullptr; c->wg_fin.loss_blocks = 0; c->wg_fin.loss_accumulate = 0;
     c->pend = 0;
     memset(&c->pend_fin, 0, sizeof(c->pend_fin));
     return VAE_OK;

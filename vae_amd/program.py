@@ -168,7 +168,12 @@ class ProgramBuilder:
         op = self._op(L.OP_ELBO, flags=(L.F_BCE if bce else 0) | (L.F_LOSS_IN_BWD if loss_in_bwd else 0),
                       r=(x_rec.ref, target_ref, mu.ref, logvar.ref, out, x_rec.gref, -1, -1),
                       d=(x_rec.n, t_sb, t_se, latent, 0, 1 if accumulate else 0))
-        self._need_scratch(op, 6, 2 * L.ELBO_BLOCKS)
+        if loss_in_bwd:
+            # the workgroups' partial pairs outlive the launch that writes them (elbo_fused_k at the head of the backward
+            # pass; summed by the weight-gradient reduction at its end): a region of their own, not the shared scratch
+            op.r[6] = self.fixed(2 * L.ELBO_BLOCKS)
+        else:
+            self._need_scratch(op, 6, 2 * L.ELBO_BLOCKS)
         return out
 
     # -- finish ---------------------------------------------------------------------------
