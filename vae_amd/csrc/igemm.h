@@ -274,7 +274,7 @@ struct IgArgs {
 
 #ifdef IG_TIMERS  // diagnostic build only: phase stamps of workgroup 1 (wall clock, 10 ns ticks)
 #define IG_TDECL long long tm_[24]; int tn_ = 0; const long long ck0_ = clock64()
-#if IG_TIMERS == 2  // wave 0's own timeline: no barrier and no wait in the stamp
+#if IG_TIMERS >= 2  // wave 0's own timeline: no barrier and no wait in the stamp
 #define IG_T() do { if (threadIdx.x == 0 && blockIdx.x == 1 && tn_ < 24) tm_[tn_++] = wall_clock64(); } while (0)
 #else
 #define IG_T() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 1 && tn_ < 24) tm_[tn_++] = wall_clock64(); } while (0)

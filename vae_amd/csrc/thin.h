@@ -556,9 +556,12 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
         }
     };
     BnFinRegs finr;
+    IG_TDECL;
+    IG_T();
     bnfin_issue<true>(a.fin, finr);
     load(blockIdx.x, sA, sAy, gA, gAy);
     load(blockIdx.x + g, sB, sBy, gB, gBy);
+    IG_T();
 
     // ---- once per workgroup
     for (int e = tid; e < 2 * imgG; e += TH_THREADS) lG[0][e] = 0.f;  // the halo stays zero
@@ -627,6 +630,7 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) bacc[j] = 0.f;
     lds_barrier();
+    IG_T();
     const float thr = cin[4 * Cin_t];
 
     // transform + store one round's registers into buffer b; the gradient values also feed the bias partials
@@ -687,17 +691,23 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
     };
 
     store(0, blockIdx.x, sA, sAy, gA, gAy);
+    IG_T();
     load(blockIdx.x + 2 * g, sA, sAy, gA, gAy);
     for (int rd = blockIdx.x; rd <= last; rd += 2 * g) {
         lds_barrier();  // buffer 0 is complete, buffer 1 is free
+        IG_T();
         compute(0, rd);
+        IG_T();
         store(1, rd + g, sB, sBy, gB, gBy);
         load(rd + 3 * g, sB, sBy, gB, gBy);
         lds_barrier();
+        IG_T();
         compute(1, rd + g);
+        IG_T();
         store(0, rd + 2 * g, sA, sAy, gA, gAy);
         load(rd + 4 * g, sA, sAy, gA, gAy);
     }
+    IG_T();
 
     // ---- cross-wave reduction (the staging buffers are dead), MT*NT tiles in passes of <= 5, and the partial row
     constexpr int TE = MT * NT * 256, RT = MT * NT < 5 ? MT * NT : 5;
@@ -734,6 +744,11 @@ __global__ __launch_bounds__(TH_THREADS) void mid_wgrad_k(MidWgArgs a) {
     } else if (tid < 64) {
         row[TE + tid] = 0.f;
     }
+    IG_T();
+#ifdef IG_TIMERS
+    if (threadIdx.x == 0 && blockIdx.x == 1) printf("mid_wgrad<%d,%d,%d> grid %d rounds %d SBR %d: issue | setup | store0 | (barrier compute barrier compute)* | loop end | reduce ...", MT, NT, (int)S_GRAD, g, nrounds, a.SBR);
+#endif
+    IG_TPRINT("");
 }
 
 // mid_conv_k<GRADIN, EPBN, ACT>: plain (non-transposed) gather of a mid-size layer: Conv forward (conv2) and ConvT input
