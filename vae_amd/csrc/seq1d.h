@@ -744,6 +744,10 @@ __device__ __forceinline__ float sq_dpre_of(float gv, float yv, const lds_f* coe
 }
 __device__ __forceinline__ void sq_dpre4(const float4& gv, const float4& yv, int e4, lds_f* dp, const lds_f* coef, int has_bn,
                                          int C, SqDiv dL, SqDiv dC, float slope) {
+    // (opaque element index: the channels -- and with them five LDS addresses per element -- are the same in every
+    // chunk, so the compiler kept them across the chunk loop of sq_bh_k, ran out of registers and spilled ten of them:
+    // scratch reloads with vmcnt waits at the head of every chunk.  Recomputing them costs a few VALU operations.)
+    asm volatile("" : "+v"(e4));
     f32x4 o;
     o.x = sq_dpre_of(gv.x, yv.x, coef, has_bn, has_bn ? sq_chan_of(4 * e4, C, dL, dC) : 0, C, slope);
     o.y = sq_dpre_of(gv.y, yv.y, coef, has_bn, has_bn ? sq_chan_of(4 * e4 + 1, C, dL, dC) : 0, C, slope);
