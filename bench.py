@@ -284,6 +284,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    out = sys.stdout
+    if world > 1:
+        # stdout carries ONE line, rank 0's JSON: whatever else writes to file descriptor 1 in a rank (gloo prints its
+        # connection messages there, from C++) goes to stderr instead
+        out = os.fdopen(os.dup(1), "w")
+        sys.stdout.flush()
+        os.dup2(2, 1)
     watchdog = None
     if world > 1 and args.rank_timeout > 0:
         # a rank started by somebody else's launcher (torchrun) has no parent of ours to end it: a collective that never
@@ -414,7 +421,7 @@ def main():
             line["strong_scaling_ref"] = strong_ref
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, B)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out, flush=True)
     if watchdog is not None:
         watchdog.cancel()
     if world > 1:
